@@ -1,0 +1,171 @@
+/*
+ * srcnn_amd.h -- C ABI of the MI355X-native SRCNN Y-channel path (libsrcnn_amd.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of rageworx/libsrcnn: the 2x "bicubic"
+ * (Mitchell) upscale of the Y plane followed by the three fixed-weight convolutions
+ * (9x9x1->64 +ReLU, 1x1x64->32 +ReLU, 5x5x32->1 +clamp).  Plain pointers and sizes only; no
+ * torch / C++ types.  Every entry point cites the reference interface it stands in for
+ * (paths relative to the reference tree, rageworx/libsrcnn v0.1.10.40).
+ *
+ * The reference's public API is C++-linkage (src/libsrcnn.h:46-54: reference parameters and a
+ * default argument).  The same shared object therefore ALSO exports the two C++ symbols
+ *     void ConfigureFilterSRCNN(SRCNNFilterType, bool)
+ *     int  ProcessSRCNN(const unsigned char*, unsigned, unsigned, unsigned, float,
+ *                       unsigned char*&, unsigned&, unsigned char**, unsigned*)
+ * declared in include/libsrcnn_dropin.h, with identical mangled names, argument meaning,
+ * ownership (caller delete[]s) and return codes -- see INTEGRATION.md.
+ *
+ * All functions return 0 on success or a negative SRCNN_E_* code; srcnn_last_error() gives the
+ * text for the calling thread.  There is NO CPU fallback: without a gfx950 device every compute
+ * entry point fails with SRCNN_E_NODEVICE.
+ *
+ * Numerics: mode SRCNN_MODE_STRICT (default) reproduces the reference's float32 results bit
+ * for bit (same operation order, separate multiply and add roundings, fp64 where the reference
+ * uses double).  SRCNN_MODE_FAST contracts multiply-add pairs to FMA (max |dY| ~2e-4 on the
+ * 0..255 scale vs the reference) and is never used unless asked for.
+ */
+#ifndef SRCNN_AMD_H
+#define SRCNN_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define SRCNN_AMD_ABI_VERSION 1
+
+/* error codes.  -1/-2/-11/-12/-100 are the reference's own (src/libsrcnn.cpp:951-966,883,910,636) */
+#define SRCNN_OK            0
+#define SRCNN_E_ARG        -1   /* NULL / zero-sized argument                    (libsrcnn.cpp:951-952) */
+#define SRCNN_E_SCALE      -2   /* non-positive scaled size                      (libsrcnn.cpp:963-966) */
+#define SRCNN_E_OUTALLOC  -11   /* output buffer allocation failed               (libsrcnn.cpp:883)     */
+#define SRCNN_E_CONVALLOC -12   /* conv-Y buffer allocation failed               (libsrcnn.cpp:910)     */
+#define SRCNN_E_NORESULT -100   /* "no RGB produced" default                     (libsrcnn.cpp:636,968) */
+#define SRCNN_E_NODEVICE -200   /* no gfx950 device / HIP runtime unusable */
+#define SRCNN_E_HIP      -201   /* a HIP call failed; see srcnn_last_error() */
+#define SRCNN_E_DEVMEM   -202   /* device allocation failed */
+#define SRCNN_E_UNSUPPORTED -203
+#define SRCNN_E_COMM     -204   /* RCCL failure */
+
+/* filter ids == SRCNNFilterType (src/libsrcnn.h:37-44) */
+#define SRCNN_FILTER_NEAREST  0
+#define SRCNN_FILTER_BILINEAR 1
+#define SRCNN_FILTER_BICUBIC  2
+#define SRCNN_FILTER_LANCZOS3 3
+#define SRCNN_FILTER_BSPLINE  4
+
+#define SRCNN_MODE_STRICT 0
+#define SRCNN_MODE_FAST   1
+
+/* ---- lifecycle (the reference has none: it is stateless CPU code; src/libsrcnn.cpp:91-92 are its
+ *      only globals).  srcnn_init is idempotent and thread-safe; every compute call self-inits on
+ *      device 0 if it was never called. ---- */
+int         srcnn_abi_version(void);
+int         srcnn_device_count(void);              /* number of visible HIP devices (0 if none) */
+int         srcnn_init(int device);                /* bind this process to `device`, upload weights */
+void        srcnn_shutdown(void);                  /* free workspaces, streams, comm */
+const char* srcnn_last_error(void);
+int         srcnn_set_mode(int mode);              /* SRCNN_MODE_*; returns previous mode or <0 */
+int         srcnn_get_mode(void);
+int         srcnn_device_name(char* buf, size_t cap);
+
+/* ---- device memory / stream / event plumbing so callers need no HIP headers ---- */
+void* srcnn_dev_alloc(size_t bytes);               /* NULL on failure */
+void  srcnn_dev_free(void* p);
+void* srcnn_host_alloc_pinned(size_t bytes);
+void  srcnn_host_free_pinned(void* p);
+int   srcnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);  /* async if stream!=NULL && pinned */
+int   srcnn_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int   srcnn_memset_dev(void* dst, int byte, size_t bytes, void* stream);
+int   srcnn_stream_create(void** stream);
+int   srcnn_stream_destroy(void* stream);
+int   srcnn_stream_sync(void* stream);             /* NULL = default stream */
+int   srcnn_device_sync(void);
+int   srcnn_event_create(void** ev);
+int   srcnn_event_destroy(void* ev);
+int   srcnn_event_record(void* ev, void* stream);
+int   srcnn_event_elapsed_ms(void* start, void* stop, float* ms);   /* syncs on `stop` */
+
+/* ---- THE HOT PATH, device-resident -------------------------------------------------------
+ * Replaces, for plane 0 (Y), the sequence in libsrcnn::doSRCNN:
+ *   FRAWResizeEngine::scale with FRAWBicubicFilter      src/libsrcnn.cpp:716-723, src/frawscale.cpp:162-385
+ *   64 x convolution99                                   src/libsrcnn.cpp:785-798 (:350-422)
+ *   32 x convolution11                                   src/libsrcnn.cpp:811-824 (:424-447)
+ *   convolution55                                        src/libsrcnn.cpp:838-846 (:449-529)
+ * d_in : planar float32 Y, w*h, row-major, values nominally 0..255 (device memory)
+ * d_out: planar float32 Y', (2w)*(2h) (device memory)
+ * Launches asynchronously on `stream` (NULL = default stream); scratch comes from a grow-only
+ * per-stream workspace owned by the library, so steady-state calls do no allocation. */
+int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_out, void* stream);
+
+/* Same for `nframes` frames stored back to back (config "batch of 64 1080p frames" /
+ * "stream of 4K frames").  Frames are independent: identical to nframes single calls. */
+int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, unsigned nframes,
+                                    float* d_out, void* stream);
+
+/* One horizontal band of the output (rows [row0,row0+rows) of the 2h output rows), computed from
+ * the whole input frame resident on this device: the multi-GPU tiling of ONE large frame
+ * (no counterpart in the reference; halo rows come from the source frame).
+ * d_out_band receives rows*2w floats.  Bit-identical to the same rows of the whole-frame call. */
+int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h,
+                                   unsigned row0, unsigned rows, float* d_out_band, void* stream);
+
+/* General Y path: resample to (dw,dh) with any SRCNNFilterType, then the three convolutions
+ * (what doSRCNN does for non-2x factors / other filters; src/libsrcnn.cpp:662-723). */
+int srcnn_y_path_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh,
+                         int filter, float* d_out, void* stream);
+
+/* ---- stage-level entry points (layer parity tests, debugging; each is one reference function) ---- */
+/* FRAWResizeEngine::scale (src/frawscale.cpp:162-286) */
+int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh,
+                           int filter, float* d_out, void* stream);
+/* 64 x convolution99 (src/libsrcnn.cpp:350-422): d_out = 64 planes of w*h */
+int srcnn_conv1_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c1, void* stream);
+/* 32 x convolution11 (src/libsrcnn.cpp:424-447): d_c1 = 64 planes, d_c2 = 32 planes */
+int srcnn_conv2_f32_dev(const float* d_c1, unsigned w, unsigned h, float* d_c2, void* stream);
+/* convolution55 (src/libsrcnn.cpp:449-529): d_c2 = 32 planes, d_out = 1 plane */
+int srcnn_conv3_f32_dev(const float* d_c2, unsigned w, unsigned h, float* d_out, void* stream);
+/* fused 64xconvolution99 + 32xconvolution11 as used by the hot path: d_c2 = 32 planes */
+int srcnn_conv12_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c2, void* stream);
+
+/* ---- host-pointer conveniences (H2D, run, D2H, synchronous) ---- */
+int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out);
+int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigned nframes, float* out);
+int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* out);
+
+/* One doSRCNN pass on an interleaved 8-bit RGB(A) image, fully on the device
+ * (src/libsrcnn.cpp:628-923): colour split :233-272, per-plane resample :665-726, Y convolutions,
+ * merge + clamp + truncate :274-308, optional truncated conv-Y :889-905.
+ * out: (w*m)*(h*m)*d bytes, conv_opt: (w*m)*(h*m) bytes or NULL; both caller-allocated host memory. */
+int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply,
+                     int filter, unsigned char* out, unsigned char* conv_opt);
+
+/* delete[] for buffers handed out by ProcessSRCNN (outbuff / *convbuff), for callers that cannot
+ * run C++ delete[] themselves (ctypes, cgo, JNI ...).  The reference leaves this to the caller. */
+void srcnn_delete_array(unsigned char* p);
+
+/* The table FRawScaleWeightsTable builds (src/frawscale.cpp:8-112), exposed for tests:
+ * returns the window size; if left/right/weights are non-NULL fills dst_len entries
+ * (weights row stride = window+1 doubles). */
+int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, int* right, double* weights);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI only for the final band gather ----
+ * The unique id is produced on rank 0 and handed to the other ranks by the caller's own
+ * bootstrap (torch.distributed/gloo store, MPI, a file ...). */
+#define SRCNN_COMM_ID_BYTES 128
+int srcnn_comm_unique_id(unsigned char id[SRCNN_COMM_ID_BYTES]);
+int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int nranks);
+int srcnn_comm_destroy(void);
+/* every rank contributes `count` floats at d_send; rank `root` receives nranks*count floats in
+ * rank order at d_recv (ignored elsewhere).  Direct peer->root sends, one xGMI link each. */
+int srcnn_comm_gather_f32(const float* d_send, size_t count, float* d_recv, int root, void* stream);
+int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, void* stream);
+int srcnn_comm_barrier(void* stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRCNN_AMD_H */

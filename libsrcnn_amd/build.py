@@ -1,0 +1,60 @@
+"""Build libsrcnn_amd.so (gfx950 code object + host C ABI + C++ drop-in) with hipcc, in-tree.
+
+Usage: python -m libsrcnn_amd.build [--force]
+The output lands in libsrcnn_amd/lib/ so that it travels with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libsrcnn_amd.so")
+
+SOURCES = ["srcnn_kernels.hip", "srcnn_capi.cpp", "srcnn_comm.cpp", "dropin.cpp"]
+DEPS = SOURCES + ["srcnn_kernels.h", "resample_table.hpp", "srcnn_weights.inc",
+                  "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h"]
+
+# -ffp-contract=off: strict kernels and the host table builder must round every multiply and add
+# separately (the reference binary contains no FMA).  FAST kernels call fmaf explicitly.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-D__HIP_PLATFORM_AMD__"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS) or os.path.getmtime(__file__) > t
+
+
+def build(force=False, verbose=True):
+    if not force and not stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

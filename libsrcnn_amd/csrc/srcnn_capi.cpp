@@ -1,0 +1,584 @@
+// srcnn_capi.cpp -- the extern "C" boundary (include/srcnn_amd.h) over the gfx950 kernels.
+//
+// Host-side orchestration only: argument validation with the reference's return codes
+// (src/libsrcnn.cpp:951-966), lazily built + cached contribution tables
+// (src/frawscale.cpp:8-112 -> resample_table.hpp), grow-only per-stream device workspaces, and the
+// launch sequence that stands in for the body of libsrcnn::doSRCNN (src/libsrcnn.cpp:628-923).
+// There is deliberately no CPU compute path in this file: if HIP is unusable the calls fail.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "../../include/srcnn_amd.h"
+#include "resample_table.hpp"
+#include "srcnn_kernels.h"
+
+namespace {
+
+using namespace srcnn;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(SRCNN_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const uint32_t kWeightBits[kWeightCount] = {
+#include "srcnn_weights.inc"
+};
+
+struct DeviceTable {
+    int* first = nullptr;
+    int* taps = nullptr;
+    double* weight = nullptr;
+    int stride = 0;
+    DevAxisTable view() const { return DevAxisTable{first, taps, weight, stride}; }
+};
+
+struct Workspace {          // scratch of one stream; grow-only
+    float* tmp = nullptr;   size_t tmp_n = 0;    // first resampler pass
+    float* up = nullptr;    size_t up_n = 0;     // upscaled Y (band)
+    float* c2 = nullptr;    size_t c2_n = 0;     // 32 layer-2 planes (band)
+    float* planes = nullptr; size_t planes_n = 0; // colour shell: split + resized chroma planes
+    unsigned char* bytes = nullptr; size_t bytes_n = 0;
+};
+
+struct Context {
+    std::mutex mu;
+    bool ready = false;
+    int device = 0;
+    int mode = SRCNN_MODE_STRICT;
+    std::map<std::tuple<int, unsigned, unsigned>, DeviceTable> tables;
+    std::map<hipStream_t, Workspace> ws;
+};
+
+Context g;
+
+void build_dev_weights(DevWeights& d)
+{
+    const float* w = reinterpret_cast<const float*>(kWeightBits);
+    const float* b1 = w;
+    const float* w1 = b1 + 64;          // [k][i][j]      (src/convdata.h:32-674)
+    const float* b2 = w1 + 64 * 81;
+    const float* w2 = b2 + 32;          // [m][f]         (src/convdata.h:686-976)
+    const float* b3 = w2 + 32 * 64;
+    const float* w3 = b3 + 1;           // [m][x][y], x = column offset (src/libsrcnn.cpp:512)
+    memset(&d, 0, sizeof d);
+    for (int k = 0; k < 64; ++k) {
+        d.b1[k] = b1[k];
+        for (int t = 0; t < 81; ++t) d.w1t[t][k] = w1[k * 81 + t];
+    }
+    for (int m = 0; m < 32; ++m) {
+        d.b2[m] = b2[m];
+        for (int f = 0; f < 64; ++f) d.w2[m][f] = w2[m * 64 + f];
+        for (int dy = 0; dy < 5; ++dy)
+            for (int dx = 0; dx < 5; ++dx) d.w3[m][dy * 5 + dx] = w3[m * 25 + dx * 5 + dy];
+    }
+    d.b3 = *b3;
+}
+
+int ensure_init_locked(int device)
+{
+    if (g.ready) {
+        if (device >= 0 && device != g.device)
+            return fail(SRCNN_E_ARG, "srcnn_init: already bound to device %d (asked for %d)", g.device, device);
+        return SRCNN_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SRCNN_E_NODEVICE, "no HIP device visible (%s); this library has no CPU path",
+                    e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0) device = 0;
+    if (device >= n) return fail(SRCNN_E_ARG, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SRCNN_E_NODEVICE, "device %d is %s; this build only carries gfx950 code", device, prop.gcnArchName);
+    auto dw = std::make_unique<DevWeights>();
+    build_dev_weights(*dw);
+    HIP_TRY(upload_weights(*dw));
+    g.device = device;
+    g.ready = true;
+    return SRCNN_OK;
+}
+
+int ensure_init()
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = ensure_init_locked(-1);
+    if (rc == SRCNN_OK) {
+        // a thread other than the one that called srcnn_init still needs the device selected
+        hipError_t e = hipSetDevice(g.device);
+        if (e != hipSuccess) return fail(SRCNN_E_HIP, "hipSetDevice(%d) -> %s", g.device, hipGetErrorString(e));
+    }
+    return rc;
+}
+
+template <class T>
+int grow(T*& p, size_t& have, size_t want)
+{
+    if (want <= have) return SRCNN_OK;
+    if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; have = 0; }
+    void* q = nullptr;
+    if (hipMalloc(&q, want * sizeof(T)) != hipSuccess)
+        return fail(SRCNN_E_DEVMEM, "hipMalloc(%zu bytes) failed", want * sizeof(T));
+    p = static_cast<T*>(q);
+    have = want;
+    return SRCNN_OK;
+}
+
+int get_table(int filter, unsigned dst_len, unsigned src_len, DeviceTable& out)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    auto key = std::make_tuple(filter, dst_len, src_len);
+    auto it = g.tables.find(key);
+    if (it != g.tables.end()) { out = it->second; return SRCNN_OK; }
+    const AxisTable t = build_axis_table(filter, dst_len, src_len);
+    DeviceTable d;
+    d.stride = t.stride;
+    HIP_TRY(hipMalloc((void**)&d.first, sizeof(int) * dst_len));
+    HIP_TRY(hipMalloc((void**)&d.taps, sizeof(int) * dst_len));
+    HIP_TRY(hipMalloc((void**)&d.weight, sizeof(double) * t.weight.size()));
+    HIP_TRY(hipMemcpy(d.first, t.first.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.taps, t.taps.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.weight, t.weight.data(), sizeof(double) * t.weight.size(), hipMemcpyHostToDevice));
+    if (g.tables.size() > 64) {   // bounded cache: drop everything (tables are cheap to rebuild)
+        hipDeviceSynchronize();
+        for (auto& kv : g.tables) { hipFree(kv.second.first); hipFree(kv.second.taps); hipFree(kv.second.weight); }
+        g.tables.clear();
+    }
+    g.tables[key] = d;
+    out = d;
+    return SRCNN_OK;
+}
+
+Workspace& workspace_for(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return g.ws[s];
+}
+
+bool strict_mode() { return g.mode == SRCNN_MODE_STRICT; }
+
+int check_plane(const void* in, unsigned w, unsigned h, const void* out)
+{
+    if (!in || !out || w == 0 || h == 0) return fail(SRCNN_E_ARG, "NULL pointer or zero dimension");
+    if ((unsigned long long)w * h > 0x7fffffffULL) return fail(SRCNN_E_UNSUPPORTED, "plane too large");
+    return SRCNN_OK;
+}
+
+// FRAWResizeEngine::scale (src/frawscale.cpp:162-286) for destination rows [r0,r1) only.
+// dst holds rows [r0,r1) (row r0 at offset 0).  tmp is scratch from the workspace.
+int resample_rows_range(const float* d_in, unsigned sw, unsigned sh, unsigned dw, unsigned dh, int filter,
+                        unsigned r0, unsigned r1, float* d_dst, Workspace& ws, hipStream_t s)
+{
+    if (sw == dw && sh == dh) {
+        // The reference's identity branch copies sizeof(unsigned short) bytes per pixel into an
+        // uninitialised buffer (src/frawscale.cpp:185-193), i.e. half the plane is garbage.  We copy the
+        // whole plane (the evident intent); documented in DESIGN.md as the one deliberate deviation.
+        HIP_TRY(hipMemcpyAsync(d_dst, d_in + (size_t)r0 * sw, sizeof(float) * (size_t)(r1 - r0) * sw,
+                               hipMemcpyDeviceToDevice, s));
+        return SRCNN_OK;
+    }
+    DeviceTable tv, th;
+    int rc;
+    if (dw <= sw) {
+        // horizontal first over all source rows, then vertical (src/frawscale.cpp:195-237)
+        const float* mid = d_in;
+        if (sw != dw) {
+            if ((rc = get_table(filter, dw, sw, th))) return rc;
+            if (sh != dh) {
+                if ((rc = grow(ws.tmp, ws.tmp_n, (size_t)dw * sh))) return rc;
+                launch_resample_rows(d_in, sw, ws.tmp, dw, sh, th.view(), s);
+                mid = ws.tmp;
+            } else {
+                launch_resample_rows(d_in + (size_t)r0 * sw, sw, d_dst, dw, r1 - r0, th.view(), s);
+                return SRCNN_OK;
+            }
+        }
+        if ((rc = get_table(filter, dh, sh, tv))) return rc;
+        launch_resample_cols(mid, dw, 0, d_dst, r0, r1 - r0, tv.view(), s);
+    } else {
+        // vertical first, then horizontal (src/frawscale.cpp:238-278)
+        if ((rc = get_table(filter, dw, sw, th))) return rc;
+        const float* mid = d_in + (size_t)r0 * sw;
+        if (sh != dh) {
+            if ((rc = get_table(filter, dh, sh, tv))) return rc;
+            if ((rc = grow(ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
+            launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, tv.view(), s);
+            mid = ws.tmp;
+        }
+        launch_resample_rows(mid, sw, d_dst, dw, r1 - r0, th.view(), s);
+    }
+    return SRCNN_OK;
+}
+
+// resample + conv12 + conv3 for output rows [r0,r1) of the (dw x dh) result.
+int y_path_rows(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+                unsigned r0, unsigned r1, float* d_out, hipStream_t s)
+{
+    if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
+    if (dh > 65535u * 4u || dw > 0x7fffffu) return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large", dw, dh);
+    Workspace& ws = workspace_for(s);
+    // rows of layer-2 activations that conv3 touches (clamp-to-edge of the ACTIVATIONS at the true
+    // border), and rows of upscaled Y that conv1 touches for those.
+    const unsigned ca = r0 >= 2 ? r0 - 2 : 0, cb = std::min(dh, r1 + 2);
+    const unsigned ua = ca >= 4 ? ca - 4 : 0, ub = std::min(dh, cb + 4);
+    int rc;
+    if ((rc = grow(ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
+    if ((rc = grow(ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
+    if ((rc = resample_rows_range(d_in, w, h, dw, dh, filter, ua, ub, ws.up, ws, s))) return rc;
+    const size_t plane = (size_t)dw * (cb - ca);
+    launch_conv12(ws.up, (int)dw, (int)dh, (int)ua, ws.c2, plane, (int)ca, (int)(cb - ca), strict_mode(), s);
+    launch_conv3(ws.c2, plane, (int)dw, (int)dh, (int)ca, (int)(cb - ca), d_out, (int)r0, (int)(r1 - r0),
+                 strict_mode(), s);
+    HIP_TRY(hipGetLastError());
+    return SRCNN_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int srcnn_abi_version(void) { return SRCNN_AMD_ABI_VERSION; }
+
+const char* srcnn_last_error(void) { return g_err; }
+
+int srcnn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int srcnn_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    return ensure_init_locked(device);
+}
+
+void srcnn_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return;
+    hipDeviceSynchronize();
+    for (auto& kv : g.tables) { hipFree(kv.second.first); hipFree(kv.second.taps); hipFree(kv.second.weight); }
+    g.tables.clear();
+    for (auto& kv : g.ws) {
+        hipFree(kv.second.tmp); hipFree(kv.second.up); hipFree(kv.second.c2);
+        hipFree(kv.second.planes); hipFree(kv.second.bytes);
+    }
+    g.ws.clear();
+    g.ready = false;
+}
+
+int srcnn_set_mode(int mode)
+{
+    if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST) return fail(SRCNN_E_ARG, "bad mode %d", mode);
+    std::lock_guard<std::mutex> lk(g.mu);
+    const int prev = g.mode;
+    g.mode = mode;
+    return prev;
+}
+
+int srcnn_get_mode(void) { return g.mode; }
+
+int srcnn_device_name(char* buf, size_t cap)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
+    snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return SRCNN_OK;
+}
+
+// ---- plumbing ----------------------------------------------------------------------------------
+void* srcnn_dev_alloc(size_t bytes)
+{
+    if (ensure_init()) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(SRCNN_E_DEVMEM, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void srcnn_dev_free(void* p) { if (p) (void)hipFree(p); }
+void* srcnn_host_alloc_pinned(size_t bytes)
+{
+    if (ensure_init()) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(SRCNN_E_DEVMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void srcnn_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
+int srcnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if (stream) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    else HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return SRCNN_OK;
+}
+int srcnn_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if (stream) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    else HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return SRCNN_OK;
+}
+int srcnn_memset_dev(void* dst, int byte, size_t bytes, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(dst, byte, bytes, (hipStream_t)stream));
+    return SRCNN_OK;
+}
+int srcnn_stream_create(void** stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return SRCNN_OK;
+}
+int srcnn_stream_destroy(void* stream)
+{
+    if (!stream) return SRCNN_OK;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        auto it = g.ws.find((hipStream_t)stream);
+        if (it != g.ws.end()) {
+            hipFree(it->second.tmp); hipFree(it->second.up); hipFree(it->second.c2);
+            hipFree(it->second.planes); hipFree(it->second.bytes);
+            g.ws.erase(it);
+        }
+    }
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return SRCNN_OK;
+}
+int srcnn_stream_sync(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return SRCNN_OK; }
+int srcnn_device_sync(void) { int rc = ensure_init(); if (rc) return rc; HIP_TRY(hipDeviceSynchronize()); return SRCNN_OK; }
+int srcnn_event_create(void** ev)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    hipEvent_t e; HIP_TRY(hipEventCreate(&e)); *ev = e; return SRCNN_OK;
+}
+int srcnn_event_destroy(void* ev) { if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return SRCNN_OK; }
+int srcnn_event_record(void* ev, void* stream) { HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return SRCNN_OK; }
+int srcnn_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SRCNN_OK;
+}
+
+// ---- the hot path ------------------------------------------------------------------------------
+int srcnn_y_path_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+                         float* d_out, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_in, w, h, d_out))) return rc;
+    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
+    return y_path_rows(d_in, w, h, dw, dh, filter, 0, dh, d_out, (hipStream_t)stream);
+}
+
+int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_out, void* stream)
+{
+    return srcnn_y_path_f32_dev(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out, stream);
+}
+
+int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out,
+                                    void* stream)
+{
+    if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
+    const size_t in_n = (size_t)w * h, out_n = in_n * 4;
+    for (unsigned f = 0; f < nframes; ++f) {
+        int rc = srcnn_y_upscale2x_f32_dev(d_in + f * in_n, w, h, d_out + f * out_n, stream);
+        if (rc) return rc;
+    }
+    return SRCNN_OK;
+}
+
+int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h, unsigned row0, unsigned rows,
+                                   float* d_out_band, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_in, w, h, d_out_band))) return rc;
+    if (rows == 0) return fail(SRCNN_E_ARG, "rows == 0");
+    return y_path_rows(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, row0, row0 + rows, d_out_band,
+                       (hipStream_t)stream);
+}
+
+// ---- stage-level -------------------------------------------------------------------------------
+int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+                           float* d_out, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_in, w, h, d_out))) return rc;
+    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
+    if (dh > 65535u || h > 65535u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
+    Workspace& ws = workspace_for((hipStream_t)stream);
+    rc = resample_rows_range(d_in, w, h, dw, dh, filter, 0, dh, d_out, ws, (hipStream_t)stream);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return SRCNN_OK;
+}
+
+int srcnn_conv1_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c1, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_y, w, h, d_c1))) return rc;
+    if (h > 65535u * 4u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
+    launch_conv1_planes(d_y, (int)w, (int)h, d_c1, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SRCNN_OK;
+}
+
+int srcnn_conv2_f32_dev(const float* d_c1, unsigned w, unsigned h, float* d_c2, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_c1, w, h, d_c2))) return rc;
+    launch_conv2_planes(d_c1, (size_t)w * h, d_c2, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SRCNN_OK;
+}
+
+int srcnn_conv3_f32_dev(const float* d_c2, unsigned w, unsigned h, float* d_out, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_c2, w, h, d_out))) return rc;
+    if (h > 65535u * 16u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
+    launch_conv3(d_c2, (size_t)w * h, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, strict_mode(), (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SRCNN_OK;
+}
+
+int srcnn_conv12_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c2, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_y, w, h, d_c2))) return rc;
+    if (h > 65535u * 4u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
+    launch_conv12(d_y, (int)w, (int)h, 0, d_c2, (size_t)w * h, 0, (int)h, strict_mode(), (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SRCNN_OK;
+}
+
+// ---- host-pointer conveniences -----------------------------------------------------------------
+int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* out)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(in, w, h, out))) return rc;
+    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    float *d_in = nullptr, *d_out = nullptr;
+    const size_t in_b = sizeof(float) * (size_t)w * h, out_b = sizeof(float) * (size_t)dw * dh;
+    if (hipMalloc((void**)&d_in, in_b) != hipSuccess || hipMalloc((void**)&d_out, out_b) != hipSuccess) {
+        hipFree(d_in);
+        return fail(SRCNN_E_DEVMEM, "device allocation of %zu+%zu bytes failed", in_b, out_b);
+    }
+    rc = SRCNN_OK;
+    if (hipMemcpy(d_in, in, in_b, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SRCNN_E_HIP, "H2D copy failed");
+    if (!rc) rc = srcnn_y_path_f32_dev(d_in, w, h, dw, dh, filter, d_out, nullptr);
+    if (!rc && hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SRCNN_E_HIP, "D2H copy failed");
+    hipFree(d_in); hipFree(d_out);
+    return rc;
+}
+
+int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out)
+{
+    return srcnn_y_path_f32(in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, out);
+}
+
+int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigned nframes, float* out)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(in, w, h, out))) return rc;
+    if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
+    // double-buffered upload / compute / download on two streams
+    const size_t in_n = (size_t)w * h, out_n = in_n * 4;
+    hipStream_t st[2]; float* din[2] = {nullptr, nullptr}; float* dout[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+        if (hipMalloc((void**)&din[i], in_n * 4) != hipSuccess || hipMalloc((void**)&dout[i], out_n * 4) != hipSuccess)
+            rc = fail(SRCNN_E_DEVMEM, "batch buffers");
+    }
+    for (unsigned f = 0; f < nframes && !rc; ++f) {
+        const int b = f & 1;
+        if (hipMemcpyAsync(din[b], in + f * in_n, in_n * 4, hipMemcpyHostToDevice, st[b]) != hipSuccess) rc = fail(SRCNN_E_HIP, "H2D");
+        if (!rc) rc = srcnn_y_upscale2x_f32_dev(din[b], w, h, dout[b], st[b]);
+        if (!rc && hipMemcpyAsync(out + f * out_n, dout[b], out_n * 4, hipMemcpyDeviceToHost, st[b]) != hipSuccess) rc = fail(SRCNN_E_HIP, "D2H");
+    }
+    for (int i = 0; i < 2; ++i) {
+        hipStreamSynchronize(st[i]);
+        srcnn_stream_destroy(st[i]);
+        hipFree(din[i]); hipFree(dout[i]);
+    }
+    return rc;
+}
+
+int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
+                     unsigned char* out, unsigned char* conv_opt)
+{
+    if (!rgb || !out || w == 0 || h == 0 || d == 0) return fail(SRCNN_E_ARG, "NULL pointer or zero dimension");
+    if (d != 3 && d != 4) return fail(SRCNN_E_UNSUPPORTED, "depth %u: the reference reads uninitialised planes for d<3 (src/libsrcnn.cpp:235-236)", d);
+    if ((float)w * multiply <= 0.f || (float)h * multiply <= 0.f) return fail(SRCNN_E_SCALE, "non-positive scaled size");
+    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
+    int rc = ensure_init(); if (rc) return rc;
+    const unsigned dw = (unsigned)((float)w * multiply), dh = (unsigned)((float)h * multiply);   // src/libsrcnn.cpp:662-663
+    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    const size_t n = (size_t)w * h, dn = (size_t)dw * dh;
+    hipStream_t s = nullptr;
+    Workspace& ws = workspace_for(s);
+    // planes: [Y Cb Cr A] at source size, then [Y' Cb' Cr' A'] at destination size
+    if ((rc = grow(ws.planes, ws.planes_n, 4 * n + 4 * dn))) return rc;
+    if ((rc = grow(ws.bytes, ws.bytes_n, n * d + dn * d + dn))) return rc;
+    float* sp[4]; float* dp[4];
+    for (int k = 0; k < 4; ++k) { sp[k] = ws.planes + k * n; dp[k] = ws.planes + 4 * n + k * dn; }
+    unsigned char* d_rgb = ws.bytes; unsigned char* d_out = ws.bytes + n * d; unsigned char* d_conv = d_out + dn * d;
+    HIP_TRY(hipMemcpyAsync(d_rgb, rgb, n * d, hipMemcpyHostToDevice, s));
+    launch_rgb_split(d_rgb, n, (int)d, sp[0], sp[1], sp[2], sp[3], s);
+    const int cfilter = (filter == SRCNN_FILTER_NEAREST) ? SRCNN_FILTER_NEAREST : SRCNN_FILTER_BILINEAR;   // src/libsrcnn.cpp:701-713
+    for (unsigned k = 1; k < d; ++k)
+        if ((rc = srcnn_resample_f32_dev(sp[k], w, h, dw, dh, cfilter, dp[k], s))) return rc;
+    if ((rc = srcnn_y_path_f32_dev(sp[0], w, h, dw, dh, filter, dp[0], s))) return rc;
+    launch_ycc_merge(dp[0], dp[1], dp[2], dp[3], dn, (int)d, d_out, conv_opt ? d_conv : nullptr, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, dn * d, hipMemcpyDeviceToHost, s));
+    if (conv_opt) HIP_TRY(hipMemcpyAsync(conv_opt, d_conv, dn, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SRCNN_OK;
+}
+
+int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, int* right, double* weights)
+{
+    if (dst_len == 0 || src_len == 0) return fail(SRCNN_E_ARG, "zero length");
+    const srcnn::AxisTable t = srcnn::build_axis_table(filter, dst_len, src_len);
+    if (left) memcpy(left, t.first.data(), sizeof(int) * dst_len);
+    if (right) memcpy(right, t.last.data(), sizeof(int) * dst_len);
+    if (weights) memcpy(weights, t.weight.data(), sizeof(double) * t.weight.size());
+    return t.window;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// srcnn_kernels.h -- internal interface between the C-ABI layer (srcnn_capi.cpp) and the gfx950
+// kernels (srcnn_kernels.hip).  Not installed; the public surface is include/srcnn_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace srcnn {
+
+constexpr int C1N = 64;   // layer-1 feature maps   (reference: CONV1_FILTERS, src/convdata.h:5)
+constexpr int C2N = 32;   // layer-2 feature maps   (reference: CONV2_FILTERS, src/convdata.h:8)
+constexpr int kWeightCount = 64 + 64 * 81 + 32 + 32 * 64 + 1 + 32 * 25;   // 8129
+
+// Device-side weight image (one __constant__ instance).  See srcnn_kernels.hip header for the
+// re-layout relative to the reference's arrays.
+struct DevWeights {
+    float w1t[81][C1N];
+    float b1[C1N];
+    float w2[C2N][C1N];
+    float b2[C2N];
+    float w3[C2N][25];
+    float b3;
+    float pad_[3];
+};
+
+struct DevAxisTable {          // device pointers into one uploaded AxisTable
+    const int* first;
+    const int* taps;
+    const double* weight;
+    int stride;
+};
+
+hipError_t upload_weights(const DevWeights& w);
+
+void launch_resample_cols(const float* src, int w, int src_row_base, float* dst, int dst_row0, int dst_rows,
+                          const DevAxisTable& t, hipStream_t s);
+void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, int rows, const DevAxisTable& t,
+                          hipStream_t s);
+void launch_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+                   int out_rows, bool strict, hipStream_t s);
+void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
+                  int out_row0, int out_rows, bool strict, hipStream_t s);
+void launch_conv1_planes(const float* Y, int W, int H, float* C1, hipStream_t s);
+void launch_conv2_planes(const float* C1, size_t n, float* C2v, hipStream_t s);
+void launch_rgb_split(const unsigned char* rgb, size_t n, int d, float* Yp, float* Cb, float* Cr, float* A,
+                      hipStream_t s);
+void launch_ycc_merge(const float* Yp, const float* Cb, const float* Cr, const float* A, size_t n, int d,
+                      unsigned char* rgb, unsigned char* conv_opt, hipStream_t s);
+
+}  // namespace srcnn

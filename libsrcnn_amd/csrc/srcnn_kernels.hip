@@ -1,0 +1,395 @@
+// srcnn_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the SRCNN Y path.
+//
+// Reference behaviour reproduced (rageworx/libsrcnn, paths relative to its tree):
+//   resample_*      FRAWResizeEngine::verticalFilter / horizontalFilter  src/frawscale.cpp:288-385
+//   conv12          64 x convolution99 + 32 x convolution11              src/libsrcnn.cpp:350-447
+//   conv3           convolution55                                        src/libsrcnn.cpp:449-529
+//   conv1 / conv2   the same two layers unfused (stage-level parity)     src/libsrcnn.cpp:350-447
+//   rgb_split / ycc_merge  colour shell                                  src/libsrcnn.cpp:233-308,889-905
+//
+// STRICT kernels keep the reference's evaluation order and roundings exactly: one rounded fp32
+// product then one rounded fp32 add per tap (no FMA; this TU is built with -ffp-contract=off and
+// the pragma below), taps in the reference's loop order, fp64 where the reference uses double.
+// FAST kernels (template parameter) contract each pair to one FMA.
+//
+// Data layout in HBM: every image is planar float32, row-major; activation stacks are
+// [channel][row][col] with a caller-given plane stride.  Weights live in __constant__ memory and
+// reach the VALU as SGPR operands (wave-uniform addresses -> s_load), re-laid out so that the
+// values one unrolled inner loop needs are contiguous:
+//   w1t[tap][k]   (tap = 9*row_off + col_off)   <- weights_conv1_data[k][row_off][col_off]
+//   w2 [m][f]                                    <- weights_conv2_data[m][f]
+//   w3 [m][dy][dx]                               <- weights_conv3_data[m][dx][dy]   (transposed!)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "srcnn_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace srcnn {
+
+__constant__ DevWeights cW;
+
+hipError_t upload_weights(const DevWeights& w)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(cW), &w, sizeof(DevWeights));
+}
+
+template <bool STRICT>
+__device__ __forceinline__ float mac(float acc, float a, float b)
+{
+    if constexpr (STRICT) return acc + a * b;          // v_mul_f32 ; v_add_f32 (contract off)
+    else return __builtin_fmaf(a, b, acc);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// =============================================================================================
+// Resampler: table-driven separable passes, fp64 multiply then fp64 add, fp32 store.
+// One thread per output sample; consecutive lanes = consecutive x (coalesced).
+// Rows are addressed in "global" row numbers with a base row per buffer so the same kernels
+// serve whole frames and horizontal bands.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_resample_cols(   // vertical pass: [src_h x w] -> rows [r0,r1) of [dst_h x w]
+    const float* __restrict__ src, int w, int src_row_base,
+    float* __restrict__ dst, int dst_row0, int dst_rows,
+    const int* __restrict__ first, const int* __restrict__ taps, const double* __restrict__ wt, int stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = dst_row0 + blockIdx.y;
+    if (x >= w || blockIdx.y >= (unsigned)dst_rows) return;
+    const int s0 = first[y], n = taps[y];
+    const double* wr = wt + (size_t)y * stride;
+    double acc = 0.0;
+    for (int t = 0; t < n; ++t) {
+        const double px = (double)src[(size_t)(s0 + t - src_row_base) * w + x];
+        acc = acc + wr[t] * px;
+    }
+    dst[(size_t)blockIdx.y * w + x] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void k_resample_rows(   // horizontal pass: [rows x src_w] -> [rows x dst_w]
+    const float* __restrict__ src, int src_w, float* __restrict__ dst, int dst_w, int rows,
+    const int* __restrict__ first, const int* __restrict__ taps, const double* __restrict__ wt, int stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dst_w || y >= rows) return;
+    const int s0 = first[x], n = taps[x];
+    const double* wr = wt + (size_t)x * stride;
+    const float* in = src + (size_t)y * src_w + s0;
+    double acc = 0.0;
+    for (int t = 0; t < n; ++t) acc = acc + wr[t] * (double)in[t];
+    dst[(size_t)y * dst_w + x] = (float)acc;
+}
+
+// =============================================================================================
+// conv12: 9x9x1->64 + ReLU, then 1x1x64->32 + ReLU, fused; the 64 intermediate planes of the
+// reference never exist.  Lane = PX output pixels of one row (x = tile_x + lane + 64*p); all 64
+// layer-1 accumulators of a pixel live in VGPRs, weights arrive as SGPRs.  The Y tile (+4 halo,
+// clamp-to-edge at the true image border) is staged once in LDS.
+//   VALU work per pixel: (5184 + 2048) x (mul + add);  LDS: 81 b32 reads;  HBM: 4 B in, 128 B out.
+// =============================================================================================
+template <int PX, bool STRICT>
+__global__ __launch_bounds__(256) void k_conv12(
+    const float* __restrict__ Y, int W, int H, int y_row_base,        // Y holds rows [y_row_base, ...)
+    float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows)  // writes rows [out_row0, +out_rows)
+{
+    constexpr int TW = 64 * PX;          // tile width  (one wave spans it)
+    constexpr int TH = 4;                // tile height (one row per wave)
+    constexpr int LW = TW + 8;
+    __shared__ float tile[(TH + 8) * LW];
+
+    const int tx0 = blockIdx.x * TW;
+    const int ty0 = out_row0 + blockIdx.y * TH;
+    for (int e = threadIdx.x; e < (TH + 8) * LW; e += 256) {
+        const int r = e / LW, c = e - r * LW;
+        const int gy = clampi(ty0 + r - 4, 0, H - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
+        tile[e] = Y[(size_t)(gy - y_row_base) * W + gx];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = ty0 + wv;
+
+    float acc[C1N][PX];
+#pragma unroll
+    for (int k = 0; k < C1N; ++k)
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[k][p] = 0.f;
+
+#pragma unroll 1
+    for (int i = 0; i < 9; ++i) {
+        float yv[9][PX];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int p = 0; p < PX; ++p) yv[j][p] = tile[(wv + i) * LW + lane + 64 * p + j];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float* wrow = cW.w1t[i * 9 + j];
+#pragma unroll
+            for (int k = 0; k < C1N; ++k) {
+                const float wk = wrow[k];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) acc[k][p] = mac<STRICT>(acc[k][p], wk, yv[j][p]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < C1N; ++k)
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[k][p] = fmaxf(acc[k][p] + cW.b1[k], 0.f);
+
+    const bool row_ok = (row < out_row0 + out_rows) && (row < H);
+#pragma unroll 2
+    for (int m = 0; m < C2N; ++m) {
+        float a[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) a[p] = 0.f;
+#pragma unroll
+        for (int f = 0; f < C1N; ++f) {
+            const float wf = cW.w2[m][f];
+#pragma unroll
+            for (int p = 0; p < PX; ++p) a[p] = mac<STRICT>(a[p], acc[f][p], wf);
+        }
+        float* dst = C2 + (size_t)m * plane_stride + (size_t)(row - out_row0) * W;
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int x = tx0 + lane + 64 * p;
+            if (row_ok && x < W) dst[x] = fmaxf(a[p] + cW.b2[m], 0.f);
+        }
+    }
+}
+
+// =============================================================================================
+// conv3: 5x5x32->1 + bias + clamp[0,255].  Per channel the reference sums fp32 products in an
+// fp64 accumulator (25 taps, row-major over the window), then folds it into an fp32 running sum.
+// Lane = 4 vertically adjacent pixels of one column; the c2 tile (+2 halo, clamp-to-edge of the
+// ACTIVATIONS at the true image border) is staged through LDS 8 channels at a time.
+// =============================================================================================
+template <bool STRICT>
+__global__ __launch_bounds__(256) void k_conv3(
+    const float* __restrict__ C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows,
+    float* __restrict__ out, int out_row0, int out_rows)
+{
+    constexpr int TW = 64, TH = 16, MC = 8;
+    constexpr int LW = TW + 4, LH = TH + 4;
+    __shared__ float tile[MC * LH * LW];
+
+    const int tx0 = blockIdx.x * TW;
+    const int ty0 = out_row0 + blockIdx.y * TH;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c2_last = c2_row_base + c2_rows - 1;
+
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int mc = 0; mc < C2N; mc += MC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < MC * LH * LW; e += 256) {
+            const int m = e / (LH * LW), rem = e - m * (LH * LW);
+            const int r = rem / LW, c = rem - r * LW;
+            int gy = clampi(ty0 + r - 2, 0, H - 1);
+            gy = clampi(gy, c2_row_base, c2_last);        // (band buffers always contain the rows they need)
+            const int gx = clampi(tx0 + c - 2, 0, W - 1);
+            tile[e] = C2[(size_t)(mc + m) * plane_stride + (size_t)(gy - c2_row_base) * W + gx];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int m = 0; m < MC; ++m) {
+            const float* t = tile + m * (LH * LW) + (wv * 4) * LW + lane;
+            const float* wm = cW.w3[mc + m];
+            float win[8][5];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) win[r][c] = t[r * LW + c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (STRICT) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 5; ++dx) {
+                            const float pr = wm[dy * 5 + dx] * win[q + dy][dx];
+                            a = a + (double)pr;
+                        }
+                    sum[q] = (float)((double)sum[q] + a);
+                } else {
+                    float a = 0.f;
+#pragma unroll
+                    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 5; ++dx) a = __builtin_fmaf(wm[dy * 5 + dx], win[q + dy][dx], a);
+                    sum[q] += a;
+                }
+            }
+        }
+    }
+    const int x = tx0 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = ty0 + wv * 4 + q;
+        if (x < W && row < H && row < out_row0 + out_rows) {
+            float v = sum[q] + cW.b3;
+            v = fminf(fmaxf(v, 0.f), 255.f);
+            out[(size_t)(row - out_row0) * W + x] = v;
+        }
+    }
+}
+
+// =============================================================================================
+// Unfused layer 1 and layer 2 (stage-level entry points; not used by the hot path).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_conv1_planes(const float* __restrict__ Y, int W, int H,
+                                                      float* __restrict__ C1, size_t plane_stride)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int k0 = blockIdx.z * 8;
+    if (x >= W || y >= H) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 9; ++i) {
+        const int gy = clampi(y + i - 4, 0, H - 1);
+        for (int j = 0; j < 9; ++j) {
+            const float v = Y[(size_t)gy * W + clampi(x + j - 4, 0, W - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = acc[k] + cW.w1t[i * 9 + j][k0 + k] * v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        C1[(size_t)(k0 + k) * plane_stride + (size_t)y * W + x] = fmaxf(acc[k] + cW.b1[k0 + k], 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_conv2_planes(const float* __restrict__ C1, size_t n,
+                                                      float* __restrict__ C2v)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * 8;
+    if (p >= n) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f = 0; f < C1N; ++f) {
+        const float v = C1[(size_t)f * n + p];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = acc[m] + v * cW.w2[m0 + m][f];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) C2v[(size_t)(m0 + m) * n + p] = fmaxf(acc[m] + cW.b2[m0 + m], 0.f);
+}
+
+// =============================================================================================
+// Colour shell (src/libsrcnn.cpp:233-308, 889-905): u8 interleaved <-> planar float.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_rgb_split(const unsigned char* __restrict__ rgb, size_t n, int d,
+                                                   float* __restrict__ Yp, float* __restrict__ Cb,
+                                                   float* __restrict__ Cr, float* __restrict__ A)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float r = (float)rgb[p * d + 0], g = (float)rgb[p * d + 1], b = (float)rgb[p * d + 2];
+    Yp[p] = (0.299f * r) + (0.587f * g) + (0.114f * b);
+    Cb[p] = 128.f - (0.1687f * r) - (0.3313f * g) + (0.5f * b);
+    Cr[p] = 128.f + (0.5f * r) - (0.4187f * g) - (0.0813f * b);
+    if (d == 4) A[p] = (float)rgb[p * d + 3];
+}
+
+__device__ __forceinline__ unsigned char to_u8_sat(float v)
+{   // MIN(255.f, v) then MAX(0.f, .) then truncating cast, in the reference's macro forms
+    v = (255.f < v) ? 255.f : v;
+    v = (0.f > v) ? 0.f : v;
+    return (unsigned char)v;
+}
+
+__global__ __launch_bounds__(256) void k_ycc_merge(const float* __restrict__ Yp, const float* __restrict__ Cb,
+                                                   const float* __restrict__ Cr, const float* __restrict__ A,
+                                                   size_t n, int d, unsigned char* __restrict__ rgb,
+                                                   unsigned char* __restrict__ conv_opt)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float fy = Yp[p], cb = Cb[p] - 128.f, cr = Cr[p] - 128.f;
+    rgb[p * d + 0] = to_u8_sat(fy + 45.f * cr / 32.f);
+    rgb[p * d + 1] = to_u8_sat(fy - (11.f * cb + 23.f * cr) / 32.f);
+    rgb[p * d + 2] = to_u8_sat(fy + 113.f * cb / 64.f);
+    if (d == 4) rgb[p * d + 3] = to_u8_sat(A[p]);
+    if (conv_opt) conv_opt[p] = (unsigned char)fy;
+}
+
+// =============================================================================================
+// Launchers.  Shapes are validated by the C-ABI layer before any launch.
+// =============================================================================================
+static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+void launch_resample_cols(const float* src, int w, int src_row_base, float* dst, int dst_row0, int dst_rows,
+                          const DevAxisTable& t, hipStream_t s)
+{
+    if (dst_rows <= 0) return;
+    dim3 grid(cdiv(w, 256), dst_rows);
+    hipLaunchKernelGGL(k_resample_cols, grid, dim3(256), 0, s, src, w, src_row_base, dst, dst_row0, dst_rows,
+                       t.first, t.taps, t.weight, t.stride);
+}
+
+void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, int rows, const DevAxisTable& t,
+                          hipStream_t s)
+{
+    if (rows <= 0) return;
+    dim3 grid(cdiv(dst_w, 256), rows);
+    hipLaunchKernelGGL(k_resample_rows, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
+                       t.weight, t.stride);
+}
+
+void launch_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+                   int out_rows, bool strict, hipStream_t s)
+{
+    if (out_rows <= 0) return;
+    constexpr int PX = 2;
+    dim3 grid(cdiv(W, 64 * PX), cdiv(out_rows, 4));
+    if (strict)
+        hipLaunchKernelGGL((k_conv12<PX, true>), grid, dim3(256), 0, s, Y, W, H, y_row_base, C2, plane_stride,
+                           out_row0, out_rows);
+    else
+        hipLaunchKernelGGL((k_conv12<PX, false>), grid, dim3(256), 0, s, Y, W, H, y_row_base, C2, plane_stride,
+                           out_row0, out_rows);
+}
+
+void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
+                  int out_row0, int out_rows, bool strict, hipStream_t s)
+{
+    if (out_rows <= 0) return;
+    dim3 grid(cdiv(W, 64), cdiv(out_rows, 16));
+    if (strict)
+        hipLaunchKernelGGL((k_conv3<true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
+                           out, out_row0, out_rows);
+    else
+        hipLaunchKernelGGL((k_conv3<false>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
+                           out, out_row0, out_rows);
+}
+
+void launch_conv1_planes(const float* Y, int W, int H, float* C1, hipStream_t s)
+{
+    dim3 grid(cdiv(W, 64), cdiv(H, 4), C1N / 8);
+    hipLaunchKernelGGL(k_conv1_planes, grid, dim3(256), 0, s, Y, W, H, C1, (size_t)W * H);
+}
+
+void launch_conv2_planes(const float* C1, size_t n, float* C2v, hipStream_t s)
+{
+    dim3 grid((unsigned)((n + 255) / 256), C2N / 8);
+    hipLaunchKernelGGL(k_conv2_planes, grid, dim3(256), 0, s, C1, n, C2v);
+}
+
+void launch_rgb_split(const unsigned char* rgb, size_t n, int d, float* Yp, float* Cb, float* Cr, float* A,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(k_rgb_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rgb, n, d, Yp, Cb, Cr, A);
+}
+
+void launch_ycc_merge(const float* Yp, const float* Cb, const float* Cr, const float* A, size_t n, int d,
+                      unsigned char* rgb, unsigned char* conv_opt, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ycc_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yp, Cb, Cr, A, n, d, rgb,
+                       conv_opt);
+}
+
+}  // namespace srcnn

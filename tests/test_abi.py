@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads, exports every symbol include/*.h declares, refuses to compute without
+a device, and its host-side table builder agrees with the oracle.  No GPU compute calls here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def S():
+    import libsrcnn_amd as S
+    if not os.path.exists(S.LIB_PATH):
+        from libsrcnn_amd import build
+        build.build(verbose=False)
+    return S
+
+
+def _declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(srcnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(S):
+    names = _declared_functions("srcnn_amd.h")
+    assert len(names) >= 40
+    L = S.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(S.C_ABI_SYMBOLS) == names, set(S.C_ABI_SYMBOLS) ^ set(names)
+
+
+def test_reference_cxx_symbols_exported(S):
+    """The reference's own mangled names (nm -D of its libsrcnn.so)."""
+    L = S.lib()
+    for sym in S.CXX_SYMBOLS:
+        assert hasattr(L, sym), sym
+    assert L.srcnn_abi_version() == 1
+
+
+def test_reference_argument_checks_need_no_device(S):
+    """ProcessSRCNN's early returns (src/libsrcnn.cpp:951-966) happen before any device work."""
+    img = np.zeros((4, 4, 3), np.uint8)
+    assert S.ProcessSRCNN(None, 4, 4, 3, 2.0)[0] == -1
+    assert S.ProcessSRCNN(img, 0, 4, 3, 2.0)[0] == -1
+    assert S.ProcessSRCNN(img, 4, 0, 3, 2.0)[0] == -1
+    assert S.ProcessSRCNN(img, 4, 4, 0, 2.0)[0] == -1
+    assert S.ProcessSRCNN(img, 4, 4, 3, 0.0)[0] == -2
+    assert S.ProcessSRCNN(img, 4, 4, 3, -1.0)[0] == -2
+
+
+def test_no_cpu_fallback(S):
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(S.SrcnnError) as e:
+        S.y_upscale2x(np.zeros((4, 4), np.float32))
+    assert e.value.code == -200
+    rc, out, conv = S.ProcessSRCNN(np.zeros((4, 4, 3), np.uint8), 4, 4, 3, 2.0)
+    assert rc == -200 and out is None
+
+
+@pytest.mark.parametrize("dst,src,filt", [(16, 8, 2), (74, 37, 2), (18, 9, 2), (10, 5, 2), (2, 1, 2), (4, 2, 2),
+                                          (6, 3, 2), (46, 23, 1), (34, 23, 3), (69, 23, 4), (9, 19, 0), (11, 19, 2),
+                                          (2160, 1080, 2), (57, 19, 1)])
+def test_axis_table_matches_oracle(S, oracle_lib, dst, src, filt):
+    a = S.axis_table(dst, src, filt)
+    b = oracle_lib.axis_table(dst, src, filt)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for u in range(dst):
+        n = a[1][u] - a[0][u] + 1
+        assert np.array_equal(a[2][u, :n].view(np.uint64), b[2][u, :n].view(np.uint64)), u
