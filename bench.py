@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- SRCNN Y-channel 2x throughput on MI355X (the metric BASELINE.json names).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload ("step"): one pass of the hot path -- 2x Mitchell upscale + conv 9x9x1->64 + conv 1x1x64->32 +
+conv 5x5x32->1, strict (bit-exact) mode -- over a batch of F synthetic 3840x2160 planar-float32 Y frames
+per GPU, producing F 7680x4320 frames.  Inputs and outputs are resident in HBM for the whole timed
+region.  Frames are independent, so ranks share nothing on the data path: each rank owns its own frames
+(weak scaling); torch.distributed (gloo) is used only for the barriers and the max-over-ranks of the time.
+
+One JSON line on rank 0.  `value` = output megapixels of ALL ranks / max-over-ranks wall time.
+`roofline` is for the dominant kernel (layers 1+2, k_conv12_mfma): its average launch duration is measured
+live inside the timed region with HIP events recorded on the launch stream by the library
+(srcnn_profile_*), and priced with the algorithmic FLOPs per launch.
+`cpu_baseline` = the reference's own OpenMP path (oracle/_ref, compiled from the reference sources) or the
+C restatement (oracle/) timed on this host's cores on a bounded sample of the same kind of frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IN_W, IN_H = 3840, 2160                   # "4K" input frame; output 7680x4320
+MAC_L12 = 64 * 81 + 32 * 64               # 7232 MAC per output pixel in the dominant kernel
+MAC_ALL = MAC_L12 + 32 * 25               # 8032
+PEAK_F32_TFLOPS = 157.3                   # MI355X_MICROARCH.md: FP32 matrix == FP32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(budget_s=20.0):
+    """Time the reference CPU path on this host: a calibration frame first, then the largest frame that
+    fits the budget.  Returns the cpu_baseline object."""
+    import oracle
+    from libsrcnn_amd import synth
+    threads = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    if oracle.have_reference():
+        eng, kind = oracle.Reference(), "reference"
+    else:
+        eng, kind = oracle.Oracle(), "port"
+    cases = [(270, 480), (540, 960), (1080, 1920), (2160, 3840)]
+    best = None
+    spent = 0.0
+    for h, w in cases:
+        y = synth.plane(h, w, synth.SEED0, "smooth")
+        t0 = time.perf_counter()
+        eng.y_path(y)
+        dt = time.perf_counter() - t0
+        spent += dt
+        best = (h, w, dt)
+        if spent + dt * 4.2 > budget_s:      # the next size is 4x the pixels
+            break
+    h, w, dt = best
+    return {"value": round(4 * h * w / 1e6 / dt, 4), "unit": "MPix/s", "cores": threads, "kind": kind,
+            "sample": "1 synthetic %dx%d -> %dx%d Y frame, %.2f s wall, OMP_NUM_THREADS=%s (layer 1 can use at most 64 "
+                      "threads, layer 2 at most 32: src/libsrcnn.cpp:791,817)" % (w, h, 2 * w, 2 * h, dt, os.environ["OMP_NUM_THREADS"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=4, help="4K frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        # CPU-side rendezvous only (barrier + max of a scalar).  The data path has no collective, and this
+        # process drives its GPU through libsrcnn_amd.so's own HIP runtime, so torch never touches the device.
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import libsrcnn_amd as S
+    from libsrcnn_amd import synth
+    S.init(local_rank)
+    S.set_mode(S.MODE_STRICT)
+    L = S.lib()
+
+    F = args.frames
+    n_in, n_out = IN_W * IN_H, 4 * IN_W * IN_H
+    d_in = S.DeviceBuffer(F * n_in * 4)
+    d_out = S.DeviceBuffer(F * n_out * 4)
+    for f in range(F):   # rank r owns frames r*F .. r*F+F-1 of the synthetic stream
+        d_in.upload(synth.plane(IN_H, IN_W, synth.SEED0 + rank * F + f, "smooth"), offset=f * n_in * 4)
+
+    def step():
+        S.check(L.srcnn_y_upscale2x_f32_batch_dev(d_in.ptr, IN_W, IN_H, F, d_out.ptr, None))
+
+    for _ in range(args.warmup):
+        step()
+    S.sync()
+
+    S.profile_reset()
+    S.profile_enable(True)
+    barrier()
+    S.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    S.sync()
+    barrier()
+    t1 = time.perf_counter()
+    S.profile_enable(False)
+    prof = S.profile_read()
+
+    ms_per_step = (t1 - t0) * 1e3 / args.steps
+    if dist is not None:
+        import torch
+        t = torch.tensor([ms_per_step], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_per_step = float(t[0])
+
+    # parity spot check on the bench's own frame 0 (not timed): a 96x160 output window against the oracle
+    max_abs = None
+    if rank == 0:
+        try:
+            import oracle
+            y0 = synth.plane(IN_H, IN_W, synth.SEED0, "smooth")
+            oy, ox, pad = 1200, 2000, 16
+            crop = y0[oy // 2 - pad:oy // 2 + 48 + pad, ox // 2 - pad:ox // 2 + 80 + pad]
+            want = oracle.Oracle().y_path(crop)[2 * pad:2 * pad + 96, 2 * pad:2 * pad + 160]
+            got = d_out.to_numpy(np.float32, (2 * IN_H, 2 * IN_W))[oy:oy + 96, ox:ox + 160]
+            max_abs = float(np.max(np.abs(got.astype(np.float64) - want)))
+        except Exception as e:     # the oracle is a checker; its absence must not fail the measurement
+            max_abs = "unchecked: %s" % e
+
+    if rank == 0:
+        mpix_step = world * F * n_out / 1e6
+        value = mpix_step / (ms_per_step * 1e-3)
+        c12_ms, c12_n = prof["conv12"]
+        avg12 = c12_ms / max(c12_n, 1)
+        flops12 = 2.0 * MAC_L12 * n_out                         # algorithmic FLOPs of one conv12 launch (one frame)
+        achieved = flops12 / (avg12 * 1e-3) / 1e12 if avg12 > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv12.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        stage = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
+        alg_bytes12 = (4 + 128) * n_out                         # layer-1+2 kernel: fp32 Y in, 32 fp32 planes out
+        out = {
+            "metric": "megapixels/sec SRCNN Y-channel (2x upscale)",
+            "value": round(value, 2), "unit": "MPix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stream of synthetic 3840x2160 Y frames -> 7680x4320 (2x), %d frames/GPU/step, frames "
+                                   "sharded across ranks, strict (bit-exact) mode" % F,
+                       "frames_per_gpu_per_step": F, "in": [IN_W, IN_H], "out": [2 * IN_W, 2 * IN_H], "mode": "strict",
+                       "parallelism": "frames sharded %d-way, no data-path collective" % world},
+            "roofline": {"kernel": "k_conv12_mfma (conv 9x9x1->64 + ReLU + conv 1x1x64->32 + ReLU)",
+                         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(avg12, 4), "launches": int(c12_n),
+                         "flops_per_launch": flops12,
+                         "note": "strict mode rounds product and sum separately (no FMA): ceiling is 0.5 of this peak",
+                         "hbm": {"algorithmic_bytes_per_launch": alg_bytes12,
+                                 "achieved_GBps": round(alg_bytes12 / (avg12 * 1e-3) / 1e9, 1) if avg12 > 0 else 0.0,
+                                 "peak_GBps": PEAK_HBM_GBS,
+                                 "frac": round(alg_bytes12 / (avg12 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if avg12 > 0 else 0.0}},
+            "stage_avg_ms_per_frame": stage,
+            "whole_path": {"tflops": round(2.0 * MAC_ALL * mpix_step * 1e6 / (ms_per_step * 1e-3) / 1e12, 3),
+                           "hbm_algorithmic_GBps": round(5 * mpix_step * 1e6 / (ms_per_step * 1e-3) / 1e9, 2)},
+            "max_abs_dY_vs_oracle": max_abs,
+            "device": S.device_name(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "unit": "MPix/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %s" % e}
+        print(json.dumps(out), flush=True)
+
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

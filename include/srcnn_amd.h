@@ -117,6 +117,19 @@ int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h,
 int srcnn_y_path_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh,
                          int filter, float* d_out, void* stream);
 
+/* ---- per-kernel timing of the hot path (what bench.py's roofline object is computed from) ----
+ * When enabled, every hot-path call brackets each of its kernels with HIP events recorded on the
+ * SAME stream the kernel is launched on.  srcnn_profile_read synchronises on the recorded events and
+ * returns, per stage, the accumulated device time and launch count since the last reset.
+ * Stages: 0 = resampler (both passes), 1 = conv 9x9 + 1x1 (layers 1+2), 2 = conv 5x5 (layer 3). */
+#define SRCNN_STAGE_RESAMPLE 0
+#define SRCNN_STAGE_CONV12   1
+#define SRCNN_STAGE_CONV3    2
+#define SRCNN_STAGE_COUNT    3
+int srcnn_profile_enable(int on);                       /* returns previous setting */
+int srcnn_profile_reset(void);
+int srcnn_profile_read(int stage, double* total_ms, unsigned long long* launches);
+
 /* ---- stage-level entry points (layer parity tests, debugging; each is one reference function) ---- */
 /* FRAWResizeEngine::scale (src/frawscale.cpp:162-286) */
 int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh,

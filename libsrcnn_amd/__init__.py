@@ -27,6 +27,7 @@ C_ABI_SYMBOLS = [
     "srcnn_memcpy_h2d", "srcnn_memcpy_d2h", "srcnn_memset_dev", "srcnn_stream_create", "srcnn_stream_destroy",
     "srcnn_stream_sync", "srcnn_device_sync", "srcnn_event_create", "srcnn_event_destroy", "srcnn_event_record",
     "srcnn_event_elapsed_ms",
+    "srcnn_profile_enable", "srcnn_profile_reset", "srcnn_profile_read",
     "srcnn_y_upscale2x_f32_dev", "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev",
     "srcnn_y_path_f32_dev", "srcnn_resample_f32_dev", "srcnn_conv1_f32_dev", "srcnn_conv2_f32_dev",
     "srcnn_conv3_f32_dev", "srcnn_conv12_f32_dev",
@@ -68,6 +69,8 @@ def lib():
             "srcnn_stream_sync": (i, [vp]), "srcnn_device_sync": (i, []),
             "srcnn_event_create": (i, [C.POINTER(vp)]), "srcnn_event_destroy": (i, [vp]),
             "srcnn_event_record": (i, [vp, vp]), "srcnn_event_elapsed_ms": (i, [vp, vp, C.POINTER(f)]),
+            "srcnn_profile_enable": (i, [i]), "srcnn_profile_reset": (i, []),
+            "srcnn_profile_read": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
             "srcnn_y_upscale2x_f32_dev": (i, [vp, u, u, vp, vp]),
             "srcnn_y_upscale2x_f32_batch_dev": (i, [vp, u, u, u, vp, vp]),
             "srcnn_y_upscale2x_f32_band_dev": (i, [vp, u, u, u, u, vp, vp]),
@@ -125,6 +128,27 @@ def set_mode(mode):
 
 def sync():
     check(lib().srcnn_device_sync())
+
+
+STAGES = ("resample", "conv12", "conv3")
+
+
+def profile_enable(on=True):
+    return lib().srcnn_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    check(lib().srcnn_profile_reset())
+
+
+def profile_read():
+    """{stage: (total_ms, launches)} accumulated by HIP events on the launch stream since the last reset."""
+    out = {}
+    for k, name in enumerate(STAGES):
+        ms, n = C.c_double(0), C.c_ulonglong(0)
+        check(lib().srcnn_profile_read(k, C.byref(ms), C.byref(n)))
+        out[name] = (ms.value, n.value)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -62,11 +63,20 @@ struct Workspace {          // scratch of one stream; grow-only
     unsigned char* bytes = nullptr; size_t bytes_n = 0;
 };
 
+struct StageSpan { hipEvent_t a, b; int stage; };
+
 struct Context {
     std::mutex mu;
+    bool profiling = false;
+    std::vector<StageSpan> spans;          // recorded, not yet read
+    std::vector<hipEvent_t> event_pool;    // recycled events
+    double stage_ms[SRCNN_STAGE_COUNT] = {0, 0, 0};
+    unsigned long long stage_n[SRCNN_STAGE_COUNT] = {0, 0, 0};
     bool ready = false;
     int device = 0;
     int mode = SRCNN_MODE_STRICT;
+    int num_cus = 256;
+    bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
     std::map<std::tuple<int, unsigned, unsigned>, DeviceTable> tables;
     std::map<hipStream_t, Workspace> ws;
 };
@@ -118,6 +128,10 @@ int ensure_init_locked(int device)
     auto dw = std::make_unique<DevWeights>();
     build_dev_weights(*dw);
     HIP_TRY(upload_weights(*dw));
+    HIP_TRY(conv12_mfma_prepare());
+    g.num_cus = prop.multiProcessorCount;
+    const char* sel = getenv("SRCNN_CONV12");
+    g.conv12_valu = sel && strcmp(sel, "valu") == 0;
     g.device = device;
     g.ready = true;
     return SRCNN_OK;
@@ -180,6 +194,53 @@ Workspace& workspace_for(hipStream_t s)
 }
 
 bool strict_mode() { return g.mode == SRCNN_MODE_STRICT; }
+
+// RAII bracket: records an event pair around one stage on the launch stream when profiling is on.
+struct StageTimer {
+    hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool on;
+    static hipEvent_t take()
+    {
+        if (!g.event_pool.empty()) { hipEvent_t e = g.event_pool.back(); g.event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    StageTimer(int stage_, hipStream_t s_) : s(s_), stage(stage_), on(g.profiling)
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g.mu);
+        a = take(); b = take();
+        if (!a || !b) { on = false; return; }
+        (void)hipEventRecord(a, s);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.spans.push_back(StageSpan{a, b, stage});
+    }
+};
+
+void drain_spans_locked()
+{
+    for (auto& sp : g.spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            g.stage_ms[sp.stage] += ms;
+            g.stage_n[sp.stage] += 1;
+        }
+        g.event_pool.push_back(sp.a);
+        g.event_pool.push_back(sp.b);
+    }
+    g.spans.clear();
+}
+
+void run_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane, int row0, int rows, hipStream_t s)
+{
+    if (g.conv12_valu) launch_conv12(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), s);
+    else launch_conv12_mfma(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), g.num_cus, s);
+}
 
 int check_plane(const void* in, unsigned w, unsigned h, const void* out)
 {
@@ -248,11 +309,20 @@ int y_path_rows(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned
     int rc;
     if ((rc = grow(ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
     if ((rc = grow(ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
-    if ((rc = resample_rows_range(d_in, w, h, dw, dh, filter, ua, ub, ws.up, ws, s))) return rc;
+    {
+        StageTimer t(SRCNN_STAGE_RESAMPLE, s);
+        if ((rc = resample_rows_range(d_in, w, h, dw, dh, filter, ua, ub, ws.up, ws, s))) return rc;
+    }
     const size_t plane = (size_t)dw * (cb - ca);
-    launch_conv12(ws.up, (int)dw, (int)dh, (int)ua, ws.c2, plane, (int)ca, (int)(cb - ca), strict_mode(), s);
-    launch_conv3(ws.c2, plane, (int)dw, (int)dh, (int)ca, (int)(cb - ca), d_out, (int)r0, (int)(r1 - r0),
-                 strict_mode(), s);
+    {
+        StageTimer t(SRCNN_STAGE_CONV12, s);
+        run_conv12(ws.up, (int)dw, (int)dh, (int)ua, ws.c2, plane, (int)ca, (int)(cb - ca), s);
+    }
+    {
+        StageTimer t(SRCNN_STAGE_CONV3, s);
+        launch_conv3(ws.c2, plane, (int)dw, (int)dh, (int)ca, (int)(cb - ca), d_out, (int)r0, (int)(r1 - r0),
+                     strict_mode(), s);
+    }
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }
@@ -431,6 +501,33 @@ int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h, un
                        (hipStream_t)stream);
 }
 
+// ---- per-kernel timing -------------------------------------------------------------------------
+int srcnn_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    const int prev = g.profiling ? 1 : 0;
+    g.profiling = on != 0;
+    return prev;
+}
+
+int srcnn_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    drain_spans_locked();
+    for (int i = 0; i < SRCNN_STAGE_COUNT; ++i) { g.stage_ms[i] = 0; g.stage_n[i] = 0; }
+    return SRCNN_OK;
+}
+
+int srcnn_profile_read(int stage, double* total_ms, unsigned long long* launches)
+{
+    if (stage < 0 || stage >= SRCNN_STAGE_COUNT) return fail(SRCNN_E_ARG, "bad stage %d", stage);
+    std::lock_guard<std::mutex> lk(g.mu);
+    drain_spans_locked();
+    if (total_ms) *total_ms = g.stage_ms[stage];
+    if (launches) *launches = g.stage_n[stage];
+    return SRCNN_OK;
+}
+
 // ---- stage-level -------------------------------------------------------------------------------
 int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
                            float* d_out, void* stream)
@@ -481,7 +578,7 @@ int srcnn_conv12_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c2, 
     int rc = ensure_init(); if (rc) return rc;
     if ((rc = check_plane(d_y, w, h, d_c2))) return rc;
     if (h > 65535u * 4u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
-    launch_conv12(d_y, (int)w, (int)h, 0, d_c2, (size_t)w * h, 0, (int)h, strict_mode(), (hipStream_t)stream);
+    run_conv12(d_y, (int)w, (int)h, 0, d_c2, (size_t)w * h, 0, (int)h, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }

@@ -21,6 +21,7 @@
 //   w3 [m][dy][dx]                               <- weights_conv3_data[m][dx][dy]   (transposed!)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "srcnn_kernels.h"
 
 #pragma clang fp contract(off)
@@ -157,6 +158,181 @@ __global__ __launch_bounds__(256) void k_conv12(
         for (int p = 0; p < PX; ++p) {
             const int x = tx0 + lane + 64 * p;
             if (row_ok && x < W) dst[x] = fmaxf(a[p] + cW.b2[m], 0.f);
+        }
+    }
+}
+
+// =============================================================================================
+// conv12 on BOTH pipes of the SIMD (the production layer-1+2 kernel).
+//
+// Strict mode may not fuse the multiply into the add, so on the VALU every MAC costs two
+// instructions.  gfx950's K=1 multi-block MFMA computes D = A (x) B + C per block with one
+// rounding (an fmaf); with C = 0 that is exactly the correctly rounded fp32 PRODUCT.  So the
+// matrix pipe produces the 64-channel x 32-pixel outer product of one tap
+//     D[k][px] = round(w1[k][tap] * Y[px + tap])          (v_mfma_f32_32x32x1_2b_f32, C = 0)
+// while the VALU only accumulates  acc[k][px] += D[k][px]  (16 v_pk_add_f32), in the reference's
+// tap order.  Elementwise adds do not care about the MFMA register layout; it matters only for the
+// bias/ReLU epilogue and the hand-off to layer 2:
+//     block b = reg/16 (lanes 32b..32b+31 feed A/B of block b), row = 8*((reg%16)/4) + 4*(lane/32) + reg%4,
+//     col = lane%32.                        A_b[row] <- lane 32b+row,   B_b[col] <- lane 32b+col
+// Layer 1: block b carries channels 32b..32b+31, both blocks see the same 32 pixels.
+// Layer 2: ReLU(c1) goes through a per-wave LDS slab [f][px]; one MFMA then multiplies channel
+//     pair (f, f+1) (block 0 / block 1) against all 32 outputs m, and the VALU adds block 0 then
+//     block 1 into acc2 -- channel order 0..63 preserved.
+// FAST mode chains C = acc instead (an FMA chain on the matrix pipe, no VALU adds).
+// =============================================================================================
+// PIN(v): an empty volatile asm that consumes and redefines v.  Instruction selection otherwise treats
+// the pure adds / MFMAs as freely movable and sinks or hoists them across the software pipeline.
+#define PIN(v) asm volatile("" : "+v"(v))
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int M_TW = 64, M_TH = 8;                 // block tile: 2 segments x 8 rows = 16 wave-segments
+constexpr int M_LW = M_TW + 8, M_LH = M_TH + 8;
+constexpr int M_W1 = 81 * 64, M_W2 = 32 * 64, M_B1 = 64, M_B2 = 32;
+constexpr int M_YT = M_LH * M_LW;
+constexpr int M_C1 = 64 * 32;                      // per-wave layer-1 slab
+constexpr int M_LDS_FLOATS = M_W1 + M_W2 + M_B1 + M_B2 + M_YT + 4 * M_C1;
+
+size_t conv12_mfma_lds_bytes() { return sizeof(float) * M_LDS_FLOATS; }
+
+template <bool STRICT>
+__global__ __launch_bounds__(256, 2) void k_conv12_mfma(
+    const float* __restrict__ Y, int W, int H, int y_row_base,
+    float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* W1s = lds;                    // [tap][lane]: lane = channel
+    float* W2s = W1s + M_W1;             // [f/2][lane]: lanes 0-31 -> w2[m=lane][f], 32-63 -> w2[m=lane-32][f+1]
+    float* B1s = W2s + M_W2;             // [half][reg] layer-1 bias in accumulator layout
+    float* B2s = B1s + M_B1;             // [half][reg] layer-2 bias in accumulator layout
+    float* Yt  = B2s + M_B2;
+    float* C1s = Yt + M_YT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
+
+    for (int e = tid; e < M_W1; e += 256) W1s[e] = (&cW.w1t[0][0])[e];
+    for (int e = tid; e < M_W2; e += 256) {
+        const int fp = e >> 6, l = e & 63;
+        W2s[e] = cW.w2[l & 31][2 * fp + (l >> 5)];
+    }
+    if (tid < 64) {
+        const int hf = tid >> 5, r = tid & 31;
+        B1s[tid] = cW.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
+    }
+    if (tid < 32) {
+        const int hf = tid >> 4, r = tid & 15;
+        B2s[tid] = cW.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
+    }
+    float* myC1 = C1s + wv * M_C1;
+    const f32x32 zero32 = {};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * M_TW, ty0 = out_row0 + tyi * M_TH;
+        __syncthreads();
+        for (int e = tid; e < M_YT; e += 256) {
+            const int r = e / M_LW, c = e - r * M_LW;
+            const int gy = clampi(ty0 + r - 4, 0, H - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
+            Yt[e] = Y[(size_t)(gy - y_row_base) * W + gx];
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            const int sg = wv * 4 + s;
+            const int trow = sg >> 1, seg = sg & 1;
+            const float* yrow = Yt + trow * M_LW + seg * 32 + col;
+
+            // ---- layer 1: 81 taps, one MFMA (products) + 16 packed adds each ----
+            // Software pipeline, pinned with sched_barrier: while the matrix pipe works on tap t+1 the VALU
+            // accumulates tap t; operands are fetched from LDS two taps ahead.  (Left alone, the scheduler
+            // hoists all 81 independent MFMAs and spills their 32-register results.)
+            f32x32 acc = zero32;
+            if constexpr (STRICT) {
+                float a1 = W1s[lane], b1 = yrow[0];
+                float a2 = W1s[64 + lane], b2 = yrow[1];
+                f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
+                a1 = a2; b1 = b2;
+                a2 = W1s[2 * 64 + lane]; b2 = yrow[2];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 81; ++t) {
+                    f32x32 d_next = zero32;
+                    if (t + 1 < 81) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    a1 = a2; b1 = b2;
+                    if (t + 3 < 81) {
+                        a2 = W1s[(t + 3) * 64 + lane];
+                        b2 = yrow[((t + 3) / 9) * M_LW + ((t + 3) % 9)];
+                    }
+                    acc += d_cur;
+                    PIN(acc);
+                    d_cur = d_next;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 81; ++t) {
+                    const float a = W1s[t * 64 + lane];
+                    const float b = yrow[(t / 9) * M_LW + (t % 9)];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, acc, 0, 0, 0);
+                }
+            }
+            // ---- bias + ReLU, hand over to layer 2 through the wave's LDS slab [f][px] ----
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const float v = fmaxf(acc[r] + B1s[half * 32 + r], 0.f);
+                const int f = 32 * (r >> 4) + 8 * ((r & 15) >> 2) + (r & 3);     // + 4*half
+                myC1[(f + 4 * half) * 32 + col] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- layer 2: 32 MFMAs, each = channels (f, f+1) x 32 outputs x 32 pixels ----
+            // A operand = activations (row index = pixel? no: A rows = outputs m must match acc2 rows),
+            // so A = weights (row m), B = activations (col px), exactly as in layer 1.
+            f32x16 acc2 = {};
+            {
+                float a1 = W2s[lane], b1 = myC1[lane];
+                float a2 = W2s[64 + lane], b2 = myC1[64 + lane];
+                f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
+                a1 = a2; b1 = b2;
+                a2 = W2s[2 * 64 + lane]; b2 = myC1[2 * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int fp = 0; fp < 32; ++fp) {
+                    f32x32 d_next = zero32;
+                    if (fp + 1 < 32) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    a1 = a2; b1 = b2;
+                    if (fp + 3 < 32) { a2 = W2s[(fp + 3) * 64 + lane]; b2 = myC1[(fp + 3) * 64 + lane]; }
+                    if constexpr (STRICT) {
+                        acc2 += __builtin_shufflevector(d_cur, d_cur, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                        acc2 += __builtin_shufflevector(d_cur, d_cur, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+                    } else {
+                        // FAST: products are still rounded (MFMA with C=0); only the adds are reassociated pairwise
+                        acc2 += __builtin_shufflevector(d_cur, d_cur, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15) +
+                                __builtin_shufflevector(d_cur, d_cur, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+                    }
+                    PIN(acc2);
+                    d_cur = d_next;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();     // slab is rewritten by the next segment
+
+            // ---- bias + ReLU + store: reg r -> output m = 8*(r/4) + 4*half + r%4, pixel col ----
+            const int row = ty0 + trow, x = tx0 + seg * 32 + col;
+            if (row < out_row0 + out_rows && row < H && x < W) {
+                float* dst = C2 + (size_t)(row - out_row0) * W + x;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 8 * (r >> 2) + (r & 3);      // + 4*half
+                    dst[(size_t)(m + 4 * half) * plane_stride] = fmaxf(acc2[r] + B2s[half * 16 + r], 0.f);
+                }
+            }
         }
     }
 }
@@ -352,6 +528,31 @@ void launch_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size
     else
         hipLaunchKernelGGL((k_conv12<PX, false>), grid, dim3(256), 0, s, Y, W, H, y_row_base, C2, plane_stride,
                            out_row0, out_rows);
+}
+
+hipError_t conv12_mfma_prepare()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv12_mfma_lds_bytes());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv12_mfma_lds_bytes());
+}
+
+void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+                        int out_rows, bool strict, int num_cus, hipStream_t s)
+{
+    if (out_rows <= 0) return;
+    const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, M_TH);
+    const int ntiles = tiles_x * tiles_y;
+    const int grid = std::min(ntiles, 2 * num_cus);     // 2 resident blocks per CU (LDS-bound), tile loop inside
+    const size_t lds = conv12_mfma_lds_bytes();
+    if (strict)
+        hipLaunchKernelGGL((k_conv12_mfma<true>), dim3(grid), dim3(256), lds, s, Y, W, H, y_row_base, C2, plane_stride,
+                           out_row0, out_rows, tiles_x, ntiles);
+    else
+        hipLaunchKernelGGL((k_conv12_mfma<false>), dim3(grid), dim3(256), lds, s, Y, W, H, y_row_base, C2, plane_stride,
+                           out_row0, out_rows, tiles_x, ntiles);
 }
 
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
