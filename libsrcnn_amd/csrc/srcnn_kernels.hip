@@ -339,47 +339,91 @@ __global__ __launch_bounds__(256, 2) void k_conv12_mfma(
 
 // =============================================================================================
 // conv3: 5x5x32->1 + bias + clamp[0,255].  Per channel the reference sums fp32 products in an
-// fp64 accumulator (25 taps, row-major over the window), then folds it into an fp32 running sum.
-// Lane = 4 vertically adjacent pixels of one column; the c2 tile (+2 halo, clamp-to-edge of the
-// ACTIVATIONS at the true image border) is staged through LDS 8 channels at a time.
+// fp64 accumulator (25 taps, row-major over the window), then folds it into an fp32 running sum:
+//     v_pk_mul_f32 (2 products) ; v_cvt_f64_f32 ; v_add_f64      -- 2.5 VALU instructions per MAC.
+// Lane = 4 vertically adjacent pixels of one column (8x5 window per channel in registers).
+// The c2 tile (+2 halo, clamp-to-edge of the ACTIVATIONS at the true image border) goes through a
+// double-buffered LDS stage, MC channels at a time: the global loads of chunk c+1 are issued before
+// the arithmetic of chunk c and land in LDS after it.  All staging index math is shifts/compares
+// (no div/mod): 64 body columns by (lane, wave) and the 4 halo columns by a second small pass.
 // =============================================================================================
+constexpr int C3_TW = 64, C3_TH = 16, C3_MC = 4;
+constexpr int C3_LW = C3_TW + 4, C3_LH = C3_TH + 4;
+constexpr int C3_CH = C3_LH * C3_LW;               // floats per staged channel
+static_assert(C3_LH % 4 == 0, "row slots");
+constexpr int C3_BODY = C3_MC * C3_LH / 4;         // body loads per thread per chunk (4 row slots)
+constexpr int C3_HALO = (C3_MC * C3_LH * 4 + 255) / 256;
+
 template <bool STRICT>
 __global__ __launch_bounds__(256) void k_conv3(
     const float* __restrict__ C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows,
     float* __restrict__ out, int out_row0, int out_rows)
 {
-    constexpr int TW = 64, TH = 16, MC = 8;
-    constexpr int LW = TW + 4, LH = TH + 4;
-    __shared__ float tile[MC * LH * LW];
+    __shared__ float tile[2][C3_MC * C3_CH];
 
-    const int tx0 = blockIdx.x * TW;
-    const int ty0 = out_row0 + blockIdx.y * TH;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tx0 = blockIdx.x * C3_TW;
+    const int ty0 = out_row0 + blockIdx.y * C3_TH;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c2_last = c2_row_base + c2_rows - 1;
+
+    // staging geometry (fixed per thread)
+    const int bx = min(tx0 + lane, W - 1);                                  // body column
+    const int hrow = tid >> 2, hq = tid & 3;                                // halo: 4 columns per staged row
+    const int hx = clampi(tx0 + (hq < 2 ? hq - 2 : 62 + hq), 0, W - 1);     // image cols tx0-2,tx0-1,tx0+64,tx0+65
+    const int hlc = hq < 2 ? hq : 64 + hq;                                  // LDS cols 0,1,66,67
+
+    float body[C3_BODY], halo[C3_HALO];
+
+    auto row_of = [&](int r) {                // staged row r (0..LH-1) -> row inside the c2 buffer
+        int gy = clampi(ty0 + r - 2, 0, H - 1);
+        gy = clampi(gy, c2_row_base, c2_last);
+        return gy - c2_row_base;
+    };
+    auto issue = [&](int mc) {                // global -> registers for chunk starting at channel mc
+#pragma unroll
+        for (int i = 0; i < C3_BODY; ++i) {
+            // staged row rr = 4*i + wv; LH is a multiple of 4, so the channel is i / (LH/4) at compile time
+            const int m = i / (C3_LH / 4), r = 4 * (i % (C3_LH / 4)) + wv;
+            body[i] = C2[(size_t)(mc + m) * plane_stride + (size_t)row_of(r) * W + bx];
+        }
+#pragma unroll
+        for (int i = 0; i < C3_HALO; ++i) {
+            const int rr = hrow + 64 * i;
+            if (rr < C3_MC * C3_LH) {
+                const int m = rr / C3_LH, r = rr - m * C3_LH;
+                halo[i] = C2[(size_t)(mc + m) * plane_stride + (size_t)row_of(r) * W + hx];
+            }
+        }
+    };
+    auto land = [&](float* dst) {             // registers -> LDS
+#pragma unroll
+        for (int i = 0; i < C3_BODY; ++i) dst[(wv + 4 * i) * C3_LW + 2 + lane] = body[i];
+#pragma unroll
+        for (int i = 0; i < C3_HALO; ++i) {
+            const int rr = hrow + 64 * i;
+            if (rr < C3_MC * C3_LH) dst[rr * C3_LW + hlc] = halo[i];
+        }
+    };
 
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
 
+    issue(0);
+    land(tile[0]);
+    __syncthreads();
+
 #pragma unroll 1
-    for (int mc = 0; mc < C2N; mc += MC) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < MC * LH * LW; e += 256) {
-            const int m = e / (LH * LW), rem = e - m * (LH * LW);
-            const int r = rem / LW, c = rem - r * LW;
-            int gy = clampi(ty0 + r - 2, 0, H - 1);
-            gy = clampi(gy, c2_row_base, c2_last);        // (band buffers always contain the rows they need)
-            const int gx = clampi(tx0 + c - 2, 0, W - 1);
-            tile[e] = C2[(size_t)(mc + m) * plane_stride + (size_t)(gy - c2_row_base) * W + gx];
-        }
-        __syncthreads();
+    for (int c = 0; c < C2N / C3_MC; ++c) {
+        const float* cur = tile[c & 1];
+        if (c + 1 < C2N / C3_MC) issue((c + 1) * C3_MC);
 #pragma unroll 1
-        for (int m = 0; m < MC; ++m) {
-            const float* t = tile + m * (LH * LW) + (wv * 4) * LW + lane;
-            const float* wm = cW.w3[mc + m];
+        for (int m = 0; m < C3_MC; ++m) {
+            const float* t = cur + m * C3_CH + (wv * 4) * C3_LW + lane;
+            const float* wm = cW.w3[c * C3_MC + m];
             float win[8][5];
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int c = 0; c < 5; ++c) win[r][c] = t[r * LW + c];
+                for (int cc = 0; cc < 5; ++cc) win[r][cc] = t[r * C3_LW + cc];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if constexpr (STRICT) {
@@ -402,6 +446,8 @@ __global__ __launch_bounds__(256) void k_conv3(
                 }
             }
         }
+        if (c + 1 < C2N / C3_MC) land(tile[(c + 1) & 1]);
+        __syncthreads();
     }
     const int x = tx0 + lane;
 #pragma unroll
