@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the committed profiles/<tag>_* files and
+profiles/pmc_conv12.json (read by bench.py for roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    for key in ("k_conv12_mfma", "k_conv12", "k_conv3", "k_resample_rows", "k_resample_cols", "k_rgb_split", "k_ycc_merge"):
+        if key in name:
+            return key
+    return name[:40]
+
+
+lines = ["# rocprofv3 summary `%s` (MI355X, `python3 bench.py`, strict mode, 3840x2160 -> 7680x4320 frames)\n" % tag]
+stats = one("kt/**/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+    lines.append("## kernel-trace --stats (`%s_kernel_stats.csv`)\n" % tag)
+    lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
+    for r in csv.DictReader(open(stats)):
+        lines.append("| %s | %s | %.4f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
+                                                       float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+pmc = {}
+for which in ("fetch", "write", "sq"):
+    f = one("pmc_%s/**/*_counter_collection.csv" % which)
+    if not f:
+        continue
+    shutil.copy(f, os.path.join(dst, "%s_pmc_%s.csv" % (tag, which)))
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in agg.items():
+        pmc.setdefault(k, {})[c] = sum(v) / len(v)
+if pmc:
+    lines.append("\n## PMC, one 3840x2160 frame per launch (separate passes; FETCH_SIZE/WRITE_SIZE are in KiB)\n")
+    cols = sorted({c for v in pmc.values() for c in v})
+    lines.append("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
+    for k, v in pmc.items():
+        lines.append("| %s | " % k + " | ".join("%.6g" % v.get(c, float("nan")) for c in cols) + " |")
+    k12 = pmc.get("k_conv12_mfma") or pmc.get("k_conv12")
+    if k12 and "FETCH_SIZE" in k12 and "WRITE_SIZE" in k12:
+        n_out = 7680 * 4320
+        fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024
+        rec = {"kernel": "k_conv12_mfma", "tag": tag, "fetch_bytes": fetch, "write_bytes": write,
+               "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 132 * n_out,
+               "note": "FETCH_SIZE taken at face value: this kernel reads 4 B/lane (the guide's x2 correction is for "
+                       "16 B/lane streams); WRITE_SIZE matches 128 B/px exactly"}
+        json.dump(rec, open(os.path.join(dst, "pmc_conv12.json"), "w"), indent=1)
+        lines.append("\nconv12 HBM traffic per launch = %.3f GB (fetch %.3f + write %.3f) vs algorithmic %.3f GB -> ratio %.3f"
+                     % ((fetch + write) / 1e9, fetch / 1e9, write / 1e9, 132 * n_out / 1e9, (fetch + write) / (132 * n_out)))
+b = one("bench.json")
+if b and os.path.getsize(b):
+    shutil.copy(b, os.path.join(dst, tag + "_bench.json"))
+    lines.append("\n## bench line of the same build (`%s_bench.json`)\n\n```\n%s```" % (tag, open(b).read()))
+open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
