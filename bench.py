@@ -97,7 +97,8 @@ def main():
 
     import libsrcnn_amd as S
     from libsrcnn_amd import synth
-    S.init(local_rank)
+    ndev = max(1, S.device_count())
+    S.init(local_rank % ndev)          # identity on a real N-GPU node; lets a 1-GPU box exercise the N>1 plumbing
     S.set_mode(S.MODE_STRICT)
     L = S.lib()
 

@@ -191,13 +191,13 @@ constexpr int M_TW = 64, M_TH = 8;                 // block tile: 2 segments x 8
 constexpr int M_LW = M_TW + 8, M_LH = M_TH + 8;
 constexpr int M_W1 = 81 * 64, M_W2 = 32 * 64, M_B1 = 64, M_B2 = 32;
 constexpr int M_YT = M_LH * M_LW;
-constexpr int M_C1 = 64 * 32;                      // per-wave layer-1 slab
+constexpr int M_C1 = 32 * 32;                      // per-wave layer-1 slab: 32 channels x 32 px (one MFMA block at a time)
 constexpr int M_LDS_FLOATS = M_W1 + M_W2 + M_B1 + M_B2 + M_YT + 4 * M_C1;
 
 size_t conv12_mfma_lds_bytes() { return sizeof(float) * M_LDS_FLOATS; }
 
 template <bool STRICT>
-__global__ __launch_bounds__(256, 2) void k_conv12_mfma(
+__global__ __launch_bounds__(256, 3) void k_conv12_mfma(
     const float* __restrict__ Y, int W, int H, int y_row_base,
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
 {
@@ -279,35 +279,37 @@ __global__ __launch_bounds__(256, 2) void k_conv12_mfma(
                     acc = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, acc, 0, 0, 0);
                 }
             }
-            // ---- bias + ReLU, hand over to layer 2 through the wave's LDS slab [f][px] ----
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const float v = fmaxf(acc[r] + B1s[half * 32 + r], 0.f);
-                const int f = 32 * (r >> 4) + 8 * ((r & 15) >> 2) + (r & 3);     // + 4*half
-                myC1[(f + 4 * half) * 32 + col] = v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-            // ---- layer 2: 32 MFMAs, each = channels (f, f+1) x 32 outputs x 32 pixels ----
-            // A operand = activations (row index = pixel? no: A rows = outputs m must match acc2 rows),
-            // so A = weights (row m), B = activations (col px), exactly as in layer 1.
+            // ---- bias + ReLU, then layer 2.  The 64 channels go through the wave's LDS slab [f][px] one MFMA
+            //      block (32 channels) at a time, so the slab is 4 KB and three blocks fit a CU. ----
             f32x16 acc2 = {};
-            {
-                float a1 = W2s[lane], b1 = myC1[lane];
-                float a2 = W2s[64 + lane], b2 = myC1[64 + lane];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(acc[16 * blk + r] + B1s[half * 32 + 16 * blk + r], 0.f);
+                    const int f = 8 * (r >> 2) + (r & 3);                  // + 4*half : channel within the block
+                    myC1[(f + 4 * half) * 32 + col] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                // 16 MFMAs per block, each = channels (f, f+1) x 32 outputs x 32 pixels; A = weights (rows = m),
+                // B = activations (cols = px); block 0 of the result is channel f, block 1 channel f+1.
+                const float* w2p = W2s + blk * 16 * 64;
+                float a1 = w2p[lane], b1 = myC1[lane];
+                float a2 = w2p[64 + lane], b2 = myC1[64 + lane];
                 f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
                 a1 = a2; b1 = b2;
-                a2 = W2s[2 * 64 + lane]; b2 = myC1[2 * 64 + lane];
+                a2 = w2p[2 * 64 + lane]; b2 = myC1[2 * 64 + lane];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int fp = 0; fp < 32; ++fp) {
+                for (int fp = 0; fp < 16; ++fp) {
                     f32x32 d_next = zero32;
-                    if (fp + 1 < 32) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
+                    if (fp + 1 < 16) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
                     __builtin_amdgcn_sched_barrier(0);
                     a1 = a2; b1 = b2;
-                    if (fp + 3 < 32) { a2 = W2s[(fp + 3) * 64 + lane]; b2 = myC1[(fp + 3) * 64 + lane]; }
+                    if (fp + 3 < 16) { a2 = w2p[(fp + 3) * 64 + lane]; b2 = myC1[(fp + 3) * 64 + lane]; }
                     if constexpr (STRICT) {
                         acc2 += __builtin_shufflevector(d_cur, d_cur, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
                         acc2 += __builtin_shufflevector(d_cur, d_cur, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
@@ -320,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void k_conv12_mfma(
                     d_cur = d_next;
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                __builtin_amdgcn_wave_barrier();     // slab is rewritten by the next block / segment
             }
-            __builtin_amdgcn_wave_barrier();     // slab is rewritten by the next segment
 
             // ---- bias + ReLU + store: reg r -> output m = 8*(r/4) + 4*half + r%4, pixel col ----
             const int row = ty0 + trow, x = tx0 + seg * 32 + col;
@@ -591,7 +593,7 @@ void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, float* C2,
     if (out_rows <= 0) return;
     const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, M_TH);
     const int ntiles = tiles_x * tiles_y;
-    const int grid = std::min(ntiles, 2 * num_cus);     // 2 resident blocks per CU (LDS-bound), tile loop inside
+    const int grid = std::min(ntiles, 3 * num_cus);     // 3 resident blocks per CU (LDS 49 KB, <=168 VGPR), tile loop inside
     const size_t lds = conv12_mfma_lds_bytes();
     if (strict)
         hipLaunchKernelGGL((k_conv12_mfma<true>), dim3(grid), dim3(256), lds, s, Y, W, H, y_row_base, C2, plane_stride,

@@ -188,3 +188,28 @@ def test_error_codes(srcnn):
     assert S.lib().srcnn_y_path_f32(buf.ctypes.data, 4, 4, 0, 8, 2, out.ctypes.data) == -2
     assert S.ProcessSRCNN(None, 4, 4, 3, 2.0)[0] == -1
     assert S.ProcessSRCNN(np.zeros((4, 4, 3), np.uint8), 4, 4, 3, -2.0)[0] == -2
+
+
+def test_rccl_comm_single_rank(srcnn):
+    """The RCCL plumbing inside the library (dlopen, unique id, init, p2p gather, all-gather, barrier) with a
+    1-rank communicator -- all a 1-GPU box can exercise; N>1 logic is covered by tests/test_multi_gpu_cpu.py."""
+    import ctypes as C
+    S = srcnn
+    L = S.lib()
+    ident = (C.c_ubyte * 128)()
+    S.check(L.srcnn_comm_unique_id(ident))
+    S.check(L.srcnn_comm_init(ident, 0, 1))
+    try:
+        x = np.arange(1000, dtype=np.float32)
+        src = S.DeviceBuffer.from_numpy(x)
+        dst = S.DeviceBuffer(x.nbytes)
+        S.check(L.srcnn_comm_gather_f32(src.ptr, x.size, dst.ptr, 0, None))
+        S.sync()
+        assert np.array_equal(dst.to_numpy(np.float32, x.shape), x)
+        dst2 = S.DeviceBuffer(x.nbytes)
+        S.check(L.srcnn_comm_allgather_f32(src.ptr, x.size, dst2.ptr, None))
+        S.sync()
+        assert np.array_equal(dst2.to_numpy(np.float32, x.shape), x)
+        S.check(L.srcnn_comm_barrier(None))
+    finally:
+        S.check(L.srcnn_comm_destroy())

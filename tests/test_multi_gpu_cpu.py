@@ -1,0 +1,111 @@
+"""CPU, world_size 2, gloo: the N>1 host logic (frame sharding, band partition, band halo, gather
+assembly).  The per-band compute is the oracle here (tests may use it); on the GPU the same functions
+drive srcnn_y_upscale2x_f32_band_dev + srcnn_comm_gather_f32."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from libsrcnn_amd import multigpu, synth  # noqa: E402
+
+
+def test_frame_sharding_is_a_partition():
+    for n in (0, 1, 7, 64, 512):
+        for world in (1, 2, 3, 8):
+            owned = [multigpu.shard_frames(n, r, world) for r in range(world)]
+            flat = sorted(i for o in owned for i in o)
+            assert flat == list(range(n))
+            assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+
+
+def test_band_rows_is_a_partition():
+    for out_h in (1, 2, 7, 90, 4320, 8640):
+        for world in (1, 2, 3, 8):
+            spans = [multigpu.band_rows(out_h, r, world) for r in range(world)]
+            pos = 0
+            for row0, rows in spans:
+                assert row0 == pos and rows >= 0
+                pos += rows
+            assert pos == out_h
+            sizes = [s[1] for s in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, shape, seed, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = oracle.Oracle()
+    y = synth.plane(shape[0], shape[1], seed, "noise")          # every rank can generate the frame
+
+    def compute_band(yy, row0, rows):
+        h = yy.shape[0]
+        lo, hi = multigpu.band_input_rows(row0, rows, h, margin=8)
+        out = orc.y_path(yy[lo:hi])                              # crop borders stay outside the band's receptive field
+        return out[row0 - 2 * lo: row0 - 2 * lo + rows]
+
+    def gather(band, counts):
+        w2 = band.shape[1]
+        bufs = [torch.empty((c, w2), dtype=torch.float32) for c in counts] if rank == 0 else None
+        # gloo gather needs equal shapes; pad to the largest band
+        mx = max(counts)
+        send = torch.zeros((mx, w2), dtype=torch.float32)
+        send[:band.shape[0]] = torch.from_numpy(band)
+        recv = [torch.empty((mx, w2), dtype=torch.float32) for _ in counts] if rank == 0 else None
+        dist.gather(send, recv, dst=0)
+        if rank != 0:
+            return None
+        return [recv[r][:counts[r]].numpy() for r in range(world)]
+
+    full = multigpu.upscale2x_frame_tiled(y, rank, world, compute_band, gather)
+    # frame-sharded batch: each rank does its own frames, then (only for the test) everything is compared on rank 0
+    frames = synth.frames(5, 20, 24, 0, "smooth")
+    mine = multigpu.shard_frames(5, rank, world)
+    outs = {i: orc.y_path(frames[i]) for i in mine}
+    allouts = [None] * world
+    dist.all_gather_object(allouts, outs)
+    if rank == 0:
+        whole = orc.y_path(y)
+        ok_tiled = bool(np.array_equal(full.view(np.uint32), whole.view(np.uint32)))
+        merged = {}
+        for d in allouts:
+            merged.update(d)
+        ok_frames = all(np.array_equal(merged[i].view(np.uint32), orc.y_path(frames[i]).view(np.uint32)) for i in range(5))
+        q.put((ok_tiled, ok_frames, full.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [(45, 40), (31, 26)])
+def test_world2_gloo_tiled_frame_and_sharded_frames(shape):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, 1234, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok_tiled, ok_frames, out_shape = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out_shape == (2 * shape[0], 2 * shape[1])
+    assert ok_tiled, "bands gathered over gloo differ from the whole-frame result"
+    assert ok_frames
