@@ -19,7 +19,7 @@ DEPS = SOURCES + ["srcnn_kernels.h", "resample_table.hpp", "srcnn_weights.inc",
 # -ffp-contract=off: strict kernels and the host table builder must round every multiply and add
 # separately (the reference binary contains no FMA).  FAST kernels call fmaf explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
-         "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-D__HIP_PLATFORM_AMD__"]
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-Wno-ignored-attributes", "-D__HIP_PLATFORM_AMD__"]
 
 
 def hipcc():

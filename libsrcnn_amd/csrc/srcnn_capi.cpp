@@ -76,6 +76,7 @@ struct Context {
     int device = 0;
     int mode = SRCNN_MODE_STRICT;
     int num_cus = 256;
+    int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
     std::map<std::tuple<int, unsigned, unsigned>, DeviceTable> tables;
     std::map<hipStream_t, Workspace> ws;
@@ -132,6 +133,8 @@ int ensure_init_locked(int device)
     g.num_cus = prop.multiProcessorCount;
     const char* sel = getenv("SRCNN_CONV12");
     g.conv12_valu = sel && strcmp(sel, "valu") == 0;
+    const char* var = getenv("SRCNN_CONV12_VARIANT");
+    g.conv12_variant = var ? atoi(var) : 1;
     g.device = device;
     g.ready = true;
     return SRCNN_OK;
@@ -239,7 +242,7 @@ void drain_spans_locked()
 void run_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane, int row0, int rows, hipStream_t s)
 {
     if (g.conv12_valu) launch_conv12(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), s);
-    else launch_conv12_mfma(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), g.num_cus, s);
+    else launch_conv12_mfma(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), g.num_cus, g.conv12_variant, s);
 }
 
 int check_plane(const void* in, unsigned w, unsigned h, const void* out)

@@ -187,32 +187,35 @@ __global__ __launch_bounds__(256) void k_conv12(
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int M_TW = 64, M_TH = 8;                 // block tile: 2 segments x 8 rows = 16 wave-segments
-constexpr int M_LW = M_TW + 8, M_LH = M_TH + 8;
+constexpr int M_TW = 64;                           // block tile: 2 segments wide, 2*NW rows -> 4 segments per wave
+constexpr int M_LW = M_TW + 8;
 constexpr int M_W1 = 81 * 64, M_W2 = 32 * 64, M_B1 = 64, M_B2 = 32;
-constexpr int M_YT = M_LH * M_LW;
 constexpr int M_C1 = 32 * 32;                      // per-wave layer-1 slab: 32 channels x 32 px (one MFMA block at a time)
-constexpr int M_LDS_FLOATS = M_W1 + M_W2 + M_B1 + M_B2 + M_YT + 4 * M_C1;
+constexpr int m_th(int nw) { return 2 * nw; }
+constexpr int m_yt(int nw) { return (m_th(nw) + 8) * M_LW; }
+constexpr int m_lds_floats(int nw) { return M_W1 + M_W2 + M_B1 + M_B2 + m_yt(nw) + nw * M_C1; }
 
-size_t conv12_mfma_lds_bytes() { return sizeof(float) * M_LDS_FLOATS; }
-
-template <bool STRICT>
-__global__ __launch_bounds__(256, 3) void k_conv12_mfma(
+// One tap-step of the product/accumulate pipeline.  PIPE=1: the MFMA of step t+1 is issued, then the VALU
+// folds in the result of step t (two result buffers).  PIPE=0: one buffer, the adds wait for their own
+// MFMA and other waves fill the gap (fewer registers -> more waves per SIMD).
+template <bool STRICT, int NW, int PIPE, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
     const float* __restrict__ Y, int W, int H, int y_row_base,
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
 {
+    constexpr int NT = 64 * NW, TH = m_th(NW), YT = m_yt(NW);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* W1s = lds;                    // [tap][lane]: lane = channel
     float* W2s = W1s + M_W1;             // [f/2][lane]: lanes 0-31 -> w2[m=lane][f], 32-63 -> w2[m=lane-32][f+1]
     float* B1s = W2s + M_W2;             // [half][reg] layer-1 bias in accumulator layout
     float* B2s = B1s + M_B1;             // [half][reg] layer-2 bias in accumulator layout
     float* Yt  = B2s + M_B2;
-    float* C1s = Yt + M_YT;
+    float* C1s = Yt + YT;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
 
-    for (int e = tid; e < M_W1; e += 256) W1s[e] = (&cW.w1t[0][0])[e];
-    for (int e = tid; e < M_W2; e += 256) {
+    for (int e = tid; e < M_W1; e += NT) W1s[e] = (&cW.w1t[0][0])[e];
+    for (int e = tid; e < M_W2; e += NT) {
         const int fp = e >> 6, l = e & 63;
         W2s[e] = cW.w2[l & 31][2 * fp + (l >> 5)];
     }
@@ -229,9 +232,9 @@ __global__ __launch_bounds__(256, 3) void k_conv12_mfma(
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int tx0 = txi * M_TW, ty0 = out_row0 + tyi * M_TH;
+        const int tx0 = txi * M_TW, ty0 = out_row0 + tyi * TH;
         __syncthreads();
-        for (int e = tid; e < M_YT; e += 256) {
+        for (int e = tid; e < YT; e += NT) {
             const int r = e / M_LW, c = e - r * M_LW;
             const int gy = clampi(ty0 + r - 4, 0, H - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
             Yt[e] = Y[(size_t)(gy - y_row_base) * W + gx];
@@ -245,11 +248,17 @@ __global__ __launch_bounds__(256, 3) void k_conv12_mfma(
             const float* yrow = Yt + trow * M_LW + seg * 32 + col;
 
             // ---- layer 1: 81 taps, one MFMA (products) + 16 packed adds each ----
-            // Software pipeline, pinned with sched_barrier: while the matrix pipe works on tap t+1 the VALU
-            // accumulates tap t; operands are fetched from LDS two taps ahead.  (Left alone, the scheduler
-            // hoists all 81 independent MFMAs and spills their 32-register results.)
+            // Pinned with sched_barrier + PIN: left alone, the scheduler hoists all 81 independent MFMAs and
+            // spills their 32-register results.  Operands are fetched from LDS two taps ahead.
             f32x32 acc = zero32;
-            if constexpr (STRICT) {
+            if constexpr (!STRICT) {
+#pragma unroll
+                for (int t = 0; t < 81; ++t) {
+                    const float a = W1s[t * 64 + lane];
+                    const float b = yrow[(t / 9) * M_LW + (t % 9)];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, acc, 0, 0, 0);
+                }
+            } else if constexpr (PIPE) {
                 float a1 = W1s[lane], b1 = yrow[0];
                 float a2 = W1s[64 + lane], b2 = yrow[1];
                 f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
@@ -272,15 +281,24 @@ __global__ __launch_bounds__(256, 3) void k_conv12_mfma(
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
+                float a1 = W1s[lane], b1 = yrow[0];
+                float a2 = W1s[64 + lane], b2 = yrow[1];
 #pragma unroll
                 for (int t = 0; t < 81; ++t) {
-                    const float a = W1s[t * 64 + lane];
-                    const float b = yrow[(t / 9) * M_LW + (t % 9)];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, acc, 0, 0, 0);
+                    f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
+                    PIN(d);
+                    a1 = a2; b1 = b2;
+                    if (t + 2 < 81) {
+                        a2 = W1s[(t + 2) * 64 + lane];
+                        b2 = yrow[((t + 2) / 9) * M_LW + ((t + 2) % 9)];
+                    }
+                    acc += d;
+                    PIN(acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // ---- bias + ReLU, then layer 2.  The 64 channels go through the wave's LDS slab [f][px] one MFMA
-            //      block (32 channels) at a time, so the slab is 4 KB and three blocks fit a CU. ----
+            //      block (32 channels) at a time, so the slab is only 4 KB per wave. ----
             f32x16 acc2 = {};
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
@@ -299,28 +317,36 @@ __global__ __launch_bounds__(256, 3) void k_conv12_mfma(
                 const float* w2p = W2s + blk * 16 * 64;
                 float a1 = w2p[lane], b1 = myC1[lane];
                 float a2 = w2p[64 + lane], b2 = myC1[64 + lane];
-                f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
-                a1 = a2; b1 = b2;
-                a2 = w2p[2 * 64 + lane]; b2 = myC1[2 * 64 + lane];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int fp = 0; fp < 16; ++fp) {
-                    f32x32 d_next = zero32;
-                    if (fp + 1 < 16) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
-                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PIPE) {
+                    f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
                     a1 = a2; b1 = b2;
-                    if (fp + 3 < 16) { a2 = w2p[(fp + 3) * 64 + lane]; b2 = myC1[(fp + 3) * 64 + lane]; }
-                    if constexpr (STRICT) {
+                    a2 = w2p[2 * 64 + lane]; b2 = myC1[2 * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int fp = 0; fp < 16; ++fp) {
+                        f32x32 d_next = zero32;
+                        if (fp + 1 < 16) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        a1 = a2; b1 = b2;
+                        if (fp + 3 < 16) { a2 = w2p[(fp + 3) * 64 + lane]; b2 = myC1[(fp + 3) * 64 + lane]; }
                         acc2 += __builtin_shufflevector(d_cur, d_cur, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
                         acc2 += __builtin_shufflevector(d_cur, d_cur, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
-                    } else {
-                        // FAST: products are still rounded (MFMA with C=0); only the adds are reassociated pairwise
-                        acc2 += __builtin_shufflevector(d_cur, d_cur, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15) +
-                                __builtin_shufflevector(d_cur, d_cur, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+                        PIN(acc2);
+                        d_cur = d_next;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    PIN(acc2);
-                    d_cur = d_next;
-                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                    for (int fp = 0; fp < 16; ++fp) {
+                        f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
+                        PIN(d);
+                        a1 = a2; b1 = b2;
+                        if (fp + 2 < 16) { a2 = w2p[(fp + 2) * 64 + lane]; b2 = myC1[(fp + 2) * 64 + lane]; }
+                        acc2 += __builtin_shufflevector(d, d, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                        acc2 += __builtin_shufflevector(d, d, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+                        PIN(acc2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();     // slab is rewritten by the next block / segment
             }
@@ -578,29 +604,54 @@ void launch_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size
                            out_row0, out_rows);
 }
 
+// Variants of the layer-1+2 kernel (selected by SRCNN_CONV12_VARIANT for A/B runs; 1 is the default, fastest
+// by 2-5 % on MI355X):
+//   0: 256 threads, pipelined (two result buffers), 3 waves/SIMD      1: 512 threads, single buffer, 4 waves/SIMD
+//   2: 256 threads, single buffer, 3 waves/SIMD                        3: 512 threads, pipelined, 2 waves/SIMD
+template <bool STRICT, int NW, int PIPE, int WPS>
+static hipError_t prep_one()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<STRICT, NW, PIPE, WPS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * m_lds_floats(NW)));
+}
+
 hipError_t conv12_mfma_prepare()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv12_mfma_lds_bytes());
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv12_mfma_lds_bytes());
+    hipError_t e;
+#define PREP(NW, PIPE, WPS)                                        \
+    if ((e = prep_one<true, NW, PIPE, WPS>()) != hipSuccess) return e; \
+    if ((e = prep_one<false, NW, PIPE, WPS>()) != hipSuccess) return e;
+    PREP(4, 1, 3) PREP(8, 0, 4) PREP(4, 0, 3) PREP(8, 1, 2)
+#undef PREP
+    return hipSuccess;
+}
+
+template <int NW, int PIPE, int WPS>
+static void launch_v(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+                     int out_rows, bool strict, int num_cus, int blocks_per_cu, hipStream_t s)
+{
+    const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, m_th(NW));
+    const int ntiles = tiles_x * tiles_y;
+    const int grid = std::min(ntiles, blocks_per_cu * num_cus);     // resident blocks only; tile loop inside
+    const size_t lds = sizeof(float) * m_lds_floats(NW);
+    if (strict)
+        hipLaunchKernelGGL((k_conv12_mfma<true, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base,
+                           C2, plane_stride, out_row0, out_rows, tiles_x, ntiles);
+    else
+        hipLaunchKernelGGL((k_conv12_mfma<false, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base,
+                           C2, plane_stride, out_row0, out_rows, tiles_x, ntiles);
 }
 
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
-                        int out_rows, bool strict, int num_cus, hipStream_t s)
+                        int out_rows, bool strict, int num_cus, int variant, hipStream_t s)
 {
     if (out_rows <= 0) return;
-    const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, M_TH);
-    const int ntiles = tiles_x * tiles_y;
-    const int grid = std::min(ntiles, 3 * num_cus);     // 3 resident blocks per CU (LDS 49 KB, <=168 VGPR), tile loop inside
-    const size_t lds = conv12_mfma_lds_bytes();
-    if (strict)
-        hipLaunchKernelGGL((k_conv12_mfma<true>), dim3(grid), dim3(256), lds, s, Y, W, H, y_row_base, C2, plane_stride,
-                           out_row0, out_rows, tiles_x, ntiles);
-    else
-        hipLaunchKernelGGL((k_conv12_mfma<false>), dim3(grid), dim3(256), lds, s, Y, W, H, y_row_base, C2, plane_stride,
-                           out_row0, out_rows, tiles_x, ntiles);
+    switch (variant) {
+    case 0: launch_v<4, 1, 3>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
+    default: launch_v<8, 0, 4>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 2, s); break;
+    case 2: launch_v<4, 0, 3>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
+    case 3: launch_v<8, 1, 2>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 1, s); break;
+    }
 }
 
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,

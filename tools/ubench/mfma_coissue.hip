@@ -13,9 +13,9 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { MFMA_ONLY, ADDS_ONLY, BOTH, BOTH_ADDS8, BOTH_ADDS12, MFMA16_BOTH, NV };
+enum { MFMA_ONLY, ADDS_ONLY, BOTH, BOTH_ADDS8, BOTH_ADDS12, MFMA16_BOTH, SCALAR_ONLY, BOTH_SCALAR, NV };
 const char* kN[NV] = {"mfma32x32x1_2b only", "16 pk_add only", "mfma32 + 16 pk_add", "mfma32 + 8 pk_add", "mfma32 + 12 pk_add",
-                      "mfma16x16x1_4b + 8 pk_add"};
+                      "mfma16x16x1_4b + 8 pk_add", "32 v_add_f32 only", "mfma32 + 32 v_add_f32"};
 
 template <int V>
 __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* clk, int iters, float a0, float b0)
@@ -74,6 +74,21 @@ __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* clk,
 #pragma unroll
             for (int i = 0; i < 16; ++i) d_cur[i] = e[i];
             __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (V == SCALAR_ONLY) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { float x = acc[i]; asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(d_cur[i])); acc[i] = x; }
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (V == BOTH_SCALAR) {
+            f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, zero, 0, 0, 0); PIN(d);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { float x = acc[i]; asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(d_cur[i])); acc[i] = x; }
+            __builtin_amdgcn_sched_barrier(0);
+            d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(b, a, zero, 0, 0, 0); PIN(d_cur);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { float x = acc[i]; asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(d[i])); acc[i] = x; }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -87,7 +102,7 @@ template <int V>
 void run(int bpc, int cus, float* d_out, unsigned long long* d_clk)
 {
     const int iters = 100000, grid = cus * bpc;
-    const int steps = (V == MFMA_ONLY || V == ADDS_ONLY) ? 1 : 2;
+    const int steps = (V == MFMA_ONLY || V == ADDS_ONLY || V == SCALAR_ONLY) ? 1 : 2;
     hipLaunchKernelGGL(k<V>, dim3(grid), dim3(256), 0, 0, d_out, d_clk, 1000, 1.0f, 0.5f);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -112,13 +127,15 @@ int main()
     const int cus = p.multiProcessorCount;
     float* d_out; hipMalloc(&d_out, sizeof(float) * 256 * cus * 4);
     unsigned long long* d_clk; hipMalloc(&d_clk, 16 * cus * 4);
-    for (int bpc : {1, 2, 3}) {
+    for (int bpc : {1, 2}) {
         run<MFMA_ONLY>(bpc, cus, d_out, d_clk);
         run<ADDS_ONLY>(bpc, cus, d_out, d_clk);
         run<BOTH>(bpc, cus, d_out, d_clk);
         run<BOTH_ADDS12>(bpc, cus, d_out, d_clk);
         run<BOTH_ADDS8>(bpc, cus, d_out, d_clk);
         run<MFMA16_BOTH>(bpc, cus, d_out, d_clk);
+        run<SCALAR_ONLY>(bpc, cus, d_out, d_clk);
+        run<BOTH_SCALAR>(bpc, cus, d_out, d_clk);
         printf("\n");
     }
     return 0;
