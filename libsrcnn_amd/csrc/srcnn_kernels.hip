@@ -452,19 +452,26 @@ __global__ __launch_bounds__(256) void k_conv3(
             for (int r = 0; r < 8; ++r)
 #pragma unroll
                 for (int cc = 0; cc < 5; ++cc) win[r][cc] = t[r * C3_LW + cc];
+            if constexpr (STRICT) {
+                // four independent fp64 chains (one per pixel) advance tap by tap, so consecutive v_add_f64 never
+                // depend on each other
+                double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if constexpr (STRICT) {
-                    double a = 0.0;
+                for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
-                    for (int dy = 0; dy < 5; ++dy)
+                    for (int dx = 0; dx < 5; ++dx) {
+                        const float wv_ = wm[dy * 5 + dx];
 #pragma unroll
-                        for (int dx = 0; dx < 5; ++dx) {
-                            const float pr = wm[dy * 5 + dx] * win[q + dy][dx];
-                            a = a + (double)pr;
+                        for (int q = 0; q < 4; ++q) {
+                            const float pr = wv_ * win[q + dy][dx];
+                            a[q] = a[q] + (double)pr;
                         }
-                    sum[q] = (float)((double)sum[q] + a);
-                } else {
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum[q] = (float)((double)sum[q] + a[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
                     float a = 0.f;
 #pragma unroll
                     for (int dy = 0; dy < 5; ++dy)
