@@ -148,12 +148,23 @@ int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out);
 int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigned nframes, float* out);
 int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* out);
 
+/* Stream of frames in host memory (config "stream of 4K frames"): two slots, each with its own HIP stream,
+ * device frame buffers and -- when use_graph != 0 -- a hipGraph captured once from the slot's kernel
+ * sequence and replayed per frame.  The caller's buffers are page-locked for the duration of the call
+ * (hipHostRegister) so H2D of frame i+1 and D2H of frame i-1 overlap the kernels of frame i.
+ * Identical results to nframes calls of srcnn_y_upscale2x_f32. */
+int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph);
+
 /* One doSRCNN pass on an interleaved 8-bit RGB(A) image, fully on the device
  * (src/libsrcnn.cpp:628-923): colour split :233-272, per-plane resample :665-726, Y convolutions,
  * merge + clamp + truncate :274-308, optional truncated conv-Y :889-905.
  * out: (w*m)*(h*m)*d bytes, conv_opt: (w*m)*(h*m) bytes or NULL; both caller-allocated host memory. */
 int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply,
                      int filter, unsigned char* out, unsigned char* conv_opt);
+
+/* Output geometry of ProcessSRCNN for (w,h,multiply) with or without step scaling: the reference only
+ * returns a byte count (outbuffsz) and truncates w*m pass by pass (src/libsrcnn.cpp:662-663, 980-1061). */
+int srcnn_output_size(unsigned w, unsigned h, float multiply, int stepscale, unsigned* out_w, unsigned* out_h);
 
 /* delete[] for buffers handed out by ProcessSRCNN (outbuff / *convbuff), for callers that cannot
  * run C++ delete[] themselves (ctypes, cgo, JNI ...).  The reference leaves this to the caller. */

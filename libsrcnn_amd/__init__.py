@@ -31,8 +31,9 @@ C_ABI_SYMBOLS = [
     "srcnn_y_upscale2x_f32_dev", "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev",
     "srcnn_y_path_f32_dev", "srcnn_resample_f32_dev", "srcnn_conv1_f32_dev", "srcnn_conv2_f32_dev",
     "srcnn_conv3_f32_dev", "srcnn_conv12_f32_dev",
-    "srcnn_y_upscale2x_f32", "srcnn_y_upscale2x_f32_batch", "srcnn_y_path_f32", "srcnn_process_u8",
-    "srcnn_delete_array", "srcnn_axis_table",
+    "srcnn_y_upscale2x_f32", "srcnn_y_upscale2x_f32_batch", "srcnn_y_upscale2x_f32_stream", "srcnn_y_path_f32",
+    "srcnn_process_u8",
+    "srcnn_delete_array", "srcnn_output_size", "srcnn_axis_table",
     "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_gather_f32",
     "srcnn_comm_allgather_f32", "srcnn_comm_barrier",
 ]
@@ -80,8 +81,10 @@ def lib():
             "srcnn_conv3_f32_dev": (i, [vp, u, u, vp, vp]), "srcnn_conv12_f32_dev": (i, [vp, u, u, vp, vp]),
             "srcnn_y_upscale2x_f32": (i, [vp, u, u, vp]), "srcnn_y_upscale2x_f32_batch": (i, [vp, u, u, u, vp]),
             "srcnn_y_path_f32": (i, [vp, u, u, u, u, i, vp]),
+            "srcnn_y_upscale2x_f32_stream": (i, [vp, u, u, u, vp, i]),
             "srcnn_process_u8": (i, [vp, u, u, u, f, i, vp, vp]),
             "srcnn_delete_array": (None, [vp]),
+            "srcnn_output_size": (i, [u, u, f, i, C.POINTER(u), C.POINTER(u)]),
             "srcnn_axis_table": (i, [i, u, u, vp, vp, vp]),
             "srcnn_comm_unique_id": (i, [vp]), "srcnn_comm_init": (i, [vp, i, i]), "srcnn_comm_destroy": (i, []),
             "srcnn_comm_gather_f32": (i, [vp, sz, vp, i, vp]), "srcnn_comm_allgather_f32": (i, [vp, sz, vp, vp]),
@@ -247,6 +250,15 @@ def y_upscale2x_batch(frames):
     return out
 
 
+def y_upscale2x_stream(frames, use_graph=True):
+    """srcnn_y_upscale2x_f32_stream: host frames in/out, two slots, optional hipGraph replay per slot."""
+    frames = np.ascontiguousarray(frames, np.float32)
+    n, h, w = frames.shape
+    out = np.empty((n, 2 * h, 2 * w), np.float32)
+    check(lib().srcnn_y_upscale2x_f32_stream(frames.ctypes.data, w, h, n, out.ctypes.data, 1 if use_graph else 0))
+    return out
+
+
 def y_path(y, dw, dh, filt=SRCNNF_Bicubic):
     y = _plane(y)
     h, w = y.shape
@@ -315,6 +327,14 @@ def axis_table(dst_len, src_len, filt=SRCNNF_Bicubic):
     w = np.zeros((dst_len, win + 1), np.float64)
     lib().srcnn_axis_table(filt, dst_len, src_len, left.ctypes.data, right.ctypes.data, w.ctypes.data)
     return left, right, w
+
+
+def output_size(w, h, multiply, stepscale=False):
+    ow, oh = C.c_uint(0), C.c_uint(0)
+    rc = lib().srcnn_output_size(w, h, float(np.float32(multiply)), 1 if stepscale else 0, C.byref(ow), C.byref(oh))
+    if rc != 0:
+        raise SrcnnError(rc, "srcnn_output_size")
+    return ow.value, oh.value
 
 
 def process_u8(rgb, multiply=2.0, filt=SRCNNF_Bicubic, want_conv=True):

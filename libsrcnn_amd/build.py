@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrcnn_amd.so")
 
 SOURCES = ["srcnn_kernels.hip", "srcnn_capi.cpp", "srcnn_comm.cpp", "dropin.cpp"]
-DEPS = SOURCES + ["srcnn_kernels.h", "resample_table.hpp", "srcnn_weights.inc",
+DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "resample_table.hpp", "srcnn_weights.inc",
                   "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h"]
 
 # -ffp-contract=off: strict kernels and the host table builder must round every multiply and add
@@ -52,7 +52,23 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return LIB
+
+
+def build_cli(verbose=True):
+    """tools/srcnntest.cpp -> libsrcnn_amd/bin/srcnntest: the counterpart of the reference's CLI harness,
+    linked against the drop-in library exactly as a libsrcnn user would link."""
+    root = os.path.dirname(HERE)
+    bindir = os.path.join(HERE, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    exe = os.path.join(bindir, "srcnntest")
+    cmd = ["g++", "-O2", "-std=c++17", os.path.join(root, "tools", "srcnntest.cpp"), "-L" + LIBDIR, "-lsrcnn_amd",
+           "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../lib", "-o", exe]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return exe
 
 
 if __name__ == "__main__":

@@ -82,3 +82,28 @@ int ProcessSRCNN(const unsigned char* refbuff, unsigned w, unsigned h, unsigned 
 }
 
 extern "C" void srcnn_delete_array(unsigned char* p) { delete[] p; }
+
+extern "C" int srcnn_output_size(unsigned w, unsigned h, float multiply, int stepscale, unsigned* out_w, unsigned* out_h)
+{
+    if (w == 0 || h == 0) return -1;
+    if ((float)w * multiply <= 0.f || (float)h * multiply <= 0.f) return -2;
+    unsigned cw = w, ch = h;
+    if (!stepscale) {
+        cw = (unsigned)((float)w * multiply); ch = (unsigned)((float)h * multiply);
+    } else {            // same pass structure as ProcessSRCNN above
+        int passes = (int)(multiply / 2.f);
+        if (fmodf(multiply, 2.f) > 0.f) ++passes;
+        for (int p = 0; p < passes; ++p) {
+            float f = 2.0f;
+            if (p + 1 == passes) {
+                f = ((float)w * multiply) / (float)cw;
+                if (f == 0.f || f == 1.0f) break;
+            }
+            cw = (unsigned)((float)cw * f); ch = (unsigned)((float)ch * f);
+        }
+    }
+    if (cw == 0 || ch == 0) return -2;
+    if (out_w) *out_w = cw;
+    if (out_h) *out_h = ch;
+    return 0;
+}

@@ -611,31 +611,67 @@ int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out)
     return srcnn_y_path_f32(in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, out);
 }
 
-int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigned nframes, float* out)
+int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph)
 {
     int rc = ensure_init(); if (rc) return rc;
     if ((rc = check_plane(in, w, h, out))) return rc;
     if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
-    // double-buffered upload / compute / download on two streams
     const size_t in_n = (size_t)w * h, out_n = in_n * 4;
-    hipStream_t st[2]; float* din[2] = {nullptr, nullptr}; float* dout[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
-        if (hipMalloc((void**)&din[i], in_n * 4) != hipSuccess || hipMalloc((void**)&dout[i], out_n * 4) != hipSuccess)
-            rc = fail(SRCNN_E_DEVMEM, "batch buffers");
+    const size_t in_b = in_n * sizeof(float), out_b = out_n * sizeof(float);
+
+    // page-lock the caller's frames so the copies are truly asynchronous; harmless if it fails
+    const bool reg_in = hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterDefault) == hipSuccess;
+    const bool reg_out = hipHostRegister(out, out_b * nframes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+
+    struct Slot { hipStream_t st = nullptr; float* din = nullptr; float* dout = nullptr; hipGraphExec_t exec = nullptr; unsigned uses = 0; };
+    Slot slot[2];
+    const int nslots = nframes > 1 ? 2 : 1;
+    for (int i = 0; i < nslots && !rc; ++i) {
+        if (hipStreamCreateWithFlags(&slot[i].st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
+        else if (hipMalloc((void**)&slot[i].din, in_b) != hipSuccess || hipMalloc((void**)&slot[i].dout, out_b) != hipSuccess)
+            rc = fail(SRCNN_E_DEVMEM, "stream slot buffers (%zu bytes)", in_b + out_b);
     }
+    const bool was_profiling = g.profiling;
     for (unsigned f = 0; f < nframes && !rc; ++f) {
-        const int b = f & 1;
-        if (hipMemcpyAsync(din[b], in + f * in_n, in_n * 4, hipMemcpyHostToDevice, st[b]) != hipSuccess) rc = fail(SRCNN_E_HIP, "H2D");
-        if (!rc) rc = srcnn_y_upscale2x_f32_dev(din[b], w, h, dout[b], st[b]);
-        if (!rc && hipMemcpyAsync(out + f * out_n, dout[b], out_n * 4, hipMemcpyDeviceToHost, st[b]) != hipSuccess) rc = fail(SRCNN_E_HIP, "D2H");
+        Slot& sl = slot[f % nslots];
+        if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "H2D"); break; }
+        if (use_graph && sl.uses >= 1 && !sl.exec) {
+            // Second use of the slot: tables and workspaces exist (first use ran eagerly), so the kernel
+            // sequence can be captured without any allocation inside the capture.
+            hipGraph_t graph = nullptr;
+            g.profiling = false;           // event pairs cannot be timed inside a capture
+            if (hipStreamBeginCapture(sl.st, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
+            if (!rc) rc = srcnn_y_upscale2x_f32_dev(sl.din, w, h, sl.dout, sl.st);
+            if (hipStreamEndCapture(sl.st, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
+            g.profiling = was_profiling;
+            if (!rc && hipGraphInstantiate(&sl.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(SRCNN_E_HIP, "graph instantiate");
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) break;
+        }
+        if (sl.exec) {
+            if (hipGraphLaunch(sl.exec, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
+        } else {
+            rc = srcnn_y_upscale2x_f32_dev(sl.din, w, h, sl.dout, sl.st);
+            if (rc) break;
+        }
+        if (hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
+        ++sl.uses;
     }
-    for (int i = 0; i < 2; ++i) {
-        hipStreamSynchronize(st[i]);
-        srcnn_stream_destroy(st[i]);
-        hipFree(din[i]); hipFree(dout[i]);
+    for (int i = 0; i < nslots; ++i) {
+        if (slot[i].st) (void)hipStreamSynchronize(slot[i].st);
+        if (slot[i].exec) (void)hipGraphExecDestroy(slot[i].exec);
+        if (slot[i].st) srcnn_stream_destroy(slot[i].st);
+        (void)hipFree(slot[i].din); (void)hipFree(slot[i].dout);
     }
+    if (reg_in) (void)hipHostUnregister(const_cast<float*>(in));
+    if (reg_out) (void)hipHostUnregister(out);
     return rc;
+}
+
+int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigned nframes, float* out)
+{
+    return srcnn_y_upscale2x_f32_stream(in, w, h, nframes, out, 0);
 }
 
 int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,

@@ -72,3 +72,16 @@ def test_axis_table_matches_oracle(S, oracle_lib, dst, src, filt):
     for u in range(dst):
         n = a[1][u] - a[0][u] + 1
         assert np.array_equal(a[2][u, :n].view(np.uint64), b[2][u, :n].view(np.uint64)), u
+
+
+def test_output_size_matches_reference_geometry(S, golden):
+    """Geometry of the golden ProcessSRCNN outputs (incl. step scaling, made by the real reference)."""
+    p = golden.process
+    assert S.output_size(256, 256, 2.0) == (512, 512)
+    h, w = p["rgb_in"].shape[:2]
+    assert S.output_size(w, h, 1.5) == p["rgb_x15_out"].shape[1::-1]
+    assert S.output_size(w, h, 3.0) == p["rgb_x3_out"].shape[1::-1]
+    assert S.output_size(24, 20, 4.0, True) == p["rgb_x4step_out"].shape[1::-1]
+    assert S.output_size(24, 20, 3.0, True) == p["rgb_x3step_out"].shape[1::-1]
+    with pytest.raises(S.SrcnnError):
+        S.output_size(0, 4, 2.0)

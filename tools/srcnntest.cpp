@@ -1,0 +1,150 @@
+// srcnntest -- command-line front end for the drop-in library, the counterpart of the reference's test
+// harness (src/test.cpp:290-448 argument handling, :533-745 main) without its FLTK / libpng dependency:
+// images are binary Netpbm (P6 RGB, P5 gray -> expanded to RGB as the reference's convImage does at
+// src/test.cpp:56-80, P7 RGB_ALPHA).
+//
+//   srcnntest [--scale=<ratio>] [--step] [--filter=<0..4>] source.ppm [output.ppm]
+//
+// Writes <source>_resized.ppm (or the given output) and <source>_convolution.pgm (the truncated SRCNN Y
+// plane), and prints the wall time of the ProcessSRCNN call like the reference ("Test Ok, took N ms.").
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/libsrcnn_dropin.h"
+#include "../include/srcnn_amd.h"
+
+namespace {
+
+bool read_token(FILE* f, std::string& tok)
+{
+    tok.clear();
+    int c;
+    while ((c = fgetc(f)) != EOF) {
+        if (c == '#') { while ((c = fgetc(f)) != EOF && c != '\n') {} continue; }
+        if (c == ' ' || c == '\t' || c == '\n' || c == '\r') { if (!tok.empty()) return true; continue; }
+        tok.push_back((char)c);
+    }
+    return !tok.empty();
+}
+
+// returns depth (3 or 4) or 0 on failure; gray input is replicated to RGB
+unsigned load_netpbm(const char* path, std::vector<unsigned char>& px, unsigned& w, unsigned& h)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return 0;
+    std::string t;
+    unsigned d = 0, src_d = 0, maxv = 255;
+    if (!read_token(f, t)) { fclose(f); return 0; }
+    if (t == "P6" || t == "P5") {
+        src_d = (t == "P6") ? 3 : 1;
+        std::string a, b, c;
+        if (!read_token(f, a) || !read_token(f, b) || !read_token(f, c)) { fclose(f); return 0; }
+        w = (unsigned)atoi(a.c_str()); h = (unsigned)atoi(b.c_str()); maxv = (unsigned)atoi(c.c_str());
+        d = 3;
+    } else if (t == "P7") {
+        std::string key, val;
+        while (read_token(f, key) && key != "ENDHDR") {
+            if (!read_token(f, val)) break;
+            if (key == "WIDTH") w = (unsigned)atoi(val.c_str());
+            else if (key == "HEIGHT") h = (unsigned)atoi(val.c_str());
+            else if (key == "DEPTH") src_d = (unsigned)atoi(val.c_str());
+            else if (key == "MAXVAL") maxv = (unsigned)atoi(val.c_str());
+        }
+        d = (src_d == 4) ? 4 : 3;
+    } else { fclose(f); return 0; }
+    if (w == 0 || h == 0 || maxv != 255 || src_d == 0 || src_d == 2 || src_d > 4) { fclose(f); return 0; }
+    std::vector<unsigned char> raw((size_t)w * h * src_d);
+    const size_t got = fread(raw.data(), 1, raw.size(), f);
+    fclose(f);
+    if (got != raw.size()) return 0;
+    if (src_d == d) { px.swap(raw); return d; }
+    px.resize((size_t)w * h * d);
+    for (size_t p = 0; p < (size_t)w * h; ++p)
+        for (unsigned k = 0; k < 3; ++k) px[p * 3 + k] = raw[p * src_d + (src_d == 1 ? 0 : k)];
+    return d;
+}
+
+bool save_netpbm(const std::string& path, const unsigned char* px, unsigned w, unsigned h, unsigned d)
+{
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    if (d == 1) fprintf(f, "P5\n%u %u\n255\n", w, h);
+    else if (d == 3) fprintf(f, "P6\n%u %u\n255\n", w, h);
+    else fprintf(f, "P7\nWIDTH %u\nHEIGHT %u\nDEPTH 4\nMAXVAL 255\nTUPLTYPE RGB_ALPHA\nENDHDR\n", w, h);
+    const bool ok = fwrite(px, 1, (size_t)w * h * d, f) == (size_t)w * h * d;
+    fclose(f);
+    return ok;
+}
+
+std::string stem(const std::string& p)
+{
+    const size_t dot = p.find_last_of('.');
+    return dot == std::string::npos ? p : p.substr(0, dot);
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    float scale = 2.0f;                      // the reference's default image_multiply (src/test.cpp:288)
+    bool step = false;
+    SRCNNFilterType filt = SRCNNF_Bicubic;
+    std::string src, dst;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a.rfind("--scale=", 0) == 0) { const float v = (float)atof(a.c_str() + 8); if (v > 0.f) scale = v; }
+        else if (a.rfind("--step", 0) == 0) step = true;
+        else if (a.rfind("--filter=", 0) == 0) {
+            const int v = atoi(a.c_str() + 9);
+            filt = (v >= 0 && v <= 4) ? (SRCNNFilterType)v : SRCNNF_Bicubic;
+        } else if (src.empty()) src = a;
+        else if (dst.empty()) dst = a;
+    }
+    if (src.empty()) {
+        printf("usage: %s [--scale=<ratio>] [--step] [--filter=<0 nearest|1 bilinear|2 bicubic|3 lanczos3|4 b-spline>] "
+               "source.(ppm|pgm|pam) [output]\n", argv[0]);
+        return 0;
+    }
+    std::vector<unsigned char> img;
+    unsigned w = 0, h = 0;
+    const unsigned d = load_netpbm(src.c_str(), img, w, h);
+    if (d == 0) { printf("- load failure: %s (binary P5/P6/P7, maxval 255 expected)\n", src.c_str()); return -1; }
+    const bool alpha = (d == 4);
+    if (dst.empty()) dst = stem(src) + "_resized" + (alpha ? ".pam" : ".ppm");
+    const std::string cov = stem(src) + "_convolution.pgm";
+
+    char dev[256] = "";
+    if (srcnn_init(0) != 0) { printf("- device init failed: %s\n", srcnn_last_error()); return -200; }
+    srcnn_device_name(dev, sizeof dev);
+    printf("- device: %s\n- Image loaded: %ux%ux%u, scaling ratio %.2f, filter %d%s\n", dev, w, h, d, scale, (int)filt,
+           step ? ", step scaling" : "");
+
+    ConfigureFilterSRCNN(filt, step);
+    unsigned char* out = nullptr; unsigned outsz = 0;
+    unsigned char* conv = nullptr; unsigned convsz = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = ProcessSRCNN(img.data(), w, h, d, scale, out, outsz, &conv, &convsz);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc != 0 || !out) { printf("- Failed, error code = %d (%s)\n", rc, srcnn_last_error()); return rc; }
+    printf("- Test Ok, took %u ms.\n", (unsigned)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+
+    unsigned ow = 0, oh = 0;
+    if (srcnn_output_size(w, h, scale, step ? 1 : 0, &ow, &oh) != 0 || (size_t)ow * oh * d != outsz) {
+        printf("- Failed: unexpected output size %u\n", outsz);
+        return -4;
+    }
+    int ret = 0;
+    if (!save_netpbm(dst, out, ow, oh, d)) { printf("- Failed to write %s\n", dst.c_str()); ret = -3; }
+    else printf("- Saved %s (%ux%ux%u)\n", dst.c_str(), ow, oh, d);
+    if (conv && convsz == ow * oh) {
+        if (save_netpbm(cov, conv, ow, oh, 1)) printf("- Saved %s\n", cov.c_str());
+    }
+    delete[] out;
+    delete[] conv;
+    srcnn_shutdown();
+    return ret;
+}
