@@ -65,6 +65,100 @@ def cpu_baseline(budget_s=20.0):
                       "threads, layer 2 at most 32: src/libsrcnn.cpp:791,817)" % (w, h, 2 * w, 2 * h, dt, os.environ["OMP_NUM_THREADS"])}
 
 
+def side_workload(args):
+    """The other BASELINE.json configurations.  Same timing protocol; reported with the same keys but they are
+    NOT the headline line the driver records (that is --workload frames)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import libsrcnn_amd as S
+    from libsrcnn_amd import synth, multigpu
+    S.init(local_rank % max(1, S.device_count()))
+    L = S.lib()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    if args.workload == "tiled8k":
+        w, h = 7680, 4320
+        y = synth.plane(h, w, synth.SEED0, "smooth")
+        d_in = S.DeviceBuffer.from_numpy(y)
+        row0, rows = multigpu.band_rows(2 * h, rank, world)
+        maxrows = multigpu.band_rows(2 * h, 0, world)[1]
+        d_band = S.DeviceBuffer(maxrows * 2 * w * 4)
+        d_full = S.DeviceBuffer(world * maxrows * 2 * w * 4) if rank == 0 else S.DeviceBuffer(16)
+        multigpu.init_comm_from_torch_dist(dist, rank, world) if world > 1 else None
+        if world == 1:
+            import ctypes as C
+            ident = (C.c_ubyte * 128)()
+            S.check(L.srcnn_comm_unique_id(ident)); S.check(L.srcnn_comm_init(ident, 0, 1))
+
+        def step():
+            S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, w, h, row0, rows, d_band.ptr, None))
+            S.check(L.srcnn_comm_gather_f32(d_band.ptr, maxrows * 2 * w, d_full.ptr, 0, None))
+        mpix_step = 4 * w * h / 1e6
+        label = "one 7680x4320 Y frame -> 15360x8640, %d output bands + RCCL gather to rank 0" % world
+    elif args.workload == "host-stream":
+        w, h, F = 3840, 2160, max(args.frames, 4)
+        import ctypes as C
+        F = max(F, 16)
+        # caller-side page-locked frame buffers (what a capture/playout pipeline would hand over)
+        pin_in = L.srcnn_host_alloc_pinned(F * w * h * 4)
+        pin_out = L.srcnn_host_alloc_pinned(F * 4 * w * h * 4)
+        frames = np.ctypeslib.as_array(C.cast(pin_in, C.POINTER(C.c_float)), (F, h, w))
+        out = np.ctypeslib.as_array(C.cast(pin_out, C.POINTER(C.c_float)), (F, 2 * h, 2 * w))
+        two = synth.frames(2, h, w, rank * F, "smooth")
+        for f in range(F):
+            frames[f] = two[f & 1]
+
+        def step():
+            S.check(L.srcnn_y_upscale2x_f32_stream(frames.ctypes.data, w, h, F, out.ctypes.data, 1))
+        mpix_step = world * F * 4 * w * h / 1e6
+        label = "%d host-resident 3840x2160 frames per rank per step, H2D + compute + D2H overlapped, hipGraph per slot" % F
+    else:
+        w, h, F = 1920, 1080, 64
+        d_in = S.DeviceBuffer(F * w * h * 4)
+        d_out = S.DeviceBuffer(F * 4 * w * h * 4)
+        for f in range(F):
+            d_in.upload(synth.plane(h, w, synth.SEED0 + rank * F + f, "smooth"), offset=f * w * h * 4)
+
+        def step():
+            S.check(L.srcnn_y_upscale2x_f32_batch_dev(d_in.ptr, w, h, F, d_out.ptr, None))
+        mpix_step = world * F * 4 * w * h / 1e6
+        label = "batch of 64 resident 1920x1080 frames per rank per step"
+
+    for _ in range(args.warmup):
+        step()
+    S.sync(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    S.sync(); barrier()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    if dist is not None:
+        import torch
+        t = torch.tensor([ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t[0])
+    if rank == 0:
+        print(json.dumps({"metric": "megapixels/sec SRCNN Y-channel (2x upscale)", "value": round(mpix_step / (ms * 1e-3), 2),
+                          "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms, 4), "higher_is_better": True,
+                          "scaling": "strong" if args.workload == "tiled8k" else "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": label, "mode": "strict"}}), flush=True)
+    barrier()
+    if args.workload == "tiled8k":
+        L.srcnn_comm_destroy()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +166,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4, help="4K frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="frames", choices=["frames", "tiled8k", "host-stream", "batch1080p"],
+                    help="frames (default, the headline metric): resident 4K frames sharded across ranks; "
+                         "tiled8k: ONE 7680x4320 frame -> 15360x8640, output bands across ranks + RCCL gather; "
+                         "host-stream: PCIe-inclusive stream of 4K frames from host memory (hipGraph per slot); "
+                         "batch1080p: 64 resident 1920x1080 frames per step")
     args = ap.parse_args()
+    if args.workload != "frames":
+        return side_workload(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

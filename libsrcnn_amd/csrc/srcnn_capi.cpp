@@ -65,6 +65,15 @@ struct Workspace {          // scratch of one stream; grow-only
 
 struct StageSpan { hipEvent_t a, b; int stage; };
 
+struct StreamSlot {         // one lane of the host-stream path; lives until srcnn_shutdown
+    hipStream_t st = nullptr;
+    float* din = nullptr;  size_t din_n = 0;
+    float* dout = nullptr; size_t dout_n = 0;
+    hipGraphExec_t exec = nullptr;     // captured kernel sequence for (gw, gh, gmode)
+    unsigned gw = 0, gh = 0; int gmode = -1;
+    unsigned uses = 0;                 // eager runs at the current shape (capture needs one first)
+};
+
 struct Context {
     std::mutex mu;
     bool profiling = false;
@@ -80,6 +89,8 @@ struct Context {
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
     std::map<std::tuple<int, unsigned, unsigned>, DeviceTable> tables;
     std::map<hipStream_t, Workspace> ws;
+    StreamSlot slots[2];
+    std::mutex stream_mu;               // srcnn_y_upscale2x_f32_stream is serialised
 };
 
 Context g;
@@ -364,6 +375,12 @@ void srcnn_shutdown(void)
         hipFree(kv.second.planes); hipFree(kv.second.bytes);
     }
     g.ws.clear();
+    for (auto& sl : g.slots) {
+        if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+        (void)hipFree(sl.din); (void)hipFree(sl.dout);
+        sl = StreamSlot();
+    }
     g.ready = false;
 }
 
@@ -624,21 +641,25 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
     const bool reg_out = hipHostRegister(out, out_b * nframes, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
 
-    struct Slot { hipStream_t st = nullptr; float* din = nullptr; float* dout = nullptr; hipGraphExec_t exec = nullptr; unsigned uses = 0; };
-    Slot slot[2];
+    std::lock_guard<std::mutex> slk(g.stream_mu);
     const int nslots = nframes > 1 ? 2 : 1;
     for (int i = 0; i < nslots && !rc; ++i) {
-        if (hipStreamCreateWithFlags(&slot[i].st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
-        else if (hipMalloc((void**)&slot[i].din, in_b) != hipSuccess || hipMalloc((void**)&slot[i].dout, out_b) != hipSuccess)
-            rc = fail(SRCNN_E_DEVMEM, "stream slot buffers (%zu bytes)", in_b + out_b);
+        StreamSlot& sl = g.slots[i];
+        if (!sl.st && hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
+        if (!rc) rc = grow(sl.din, sl.din_n, in_n);
+        if (!rc) rc = grow(sl.dout, sl.dout_n, out_n);
+        if (sl.exec && (sl.gw != w || sl.gh != h || sl.gmode != g.mode)) {     // shape or mode changed: drop the graph
+            (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; sl.uses = 0;
+        }
+        if (sl.gw != w || sl.gh != h || sl.gmode != g.mode) { sl.gw = w; sl.gh = h; sl.gmode = g.mode; sl.uses = 0; }
     }
     const bool was_profiling = g.profiling;
     for (unsigned f = 0; f < nframes && !rc; ++f) {
-        Slot& sl = slot[f % nslots];
+        StreamSlot& sl = g.slots[f % nslots];
         if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "H2D"); break; }
         if (use_graph && sl.uses >= 1 && !sl.exec) {
-            // Second use of the slot: tables and workspaces exist (first use ran eagerly), so the kernel
-            // sequence can be captured without any allocation inside the capture.
+            // The slot has run this shape eagerly once: tables and workspaces exist, so the kernel sequence
+            // can be captured without any allocation inside the capture.
             hipGraph_t graph = nullptr;
             g.profiling = false;           // event pairs cannot be timed inside a capture
             if (hipStreamBeginCapture(sl.st, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
@@ -649,7 +670,7 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
             if (graph) (void)hipGraphDestroy(graph);
             if (rc) break;
         }
-        if (sl.exec) {
+        if (use_graph && sl.exec) {
             if (hipGraphLaunch(sl.exec, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
         } else {
             rc = srcnn_y_upscale2x_f32_dev(sl.din, w, h, sl.dout, sl.st);
@@ -658,12 +679,8 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
         if (hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
         ++sl.uses;
     }
-    for (int i = 0; i < nslots; ++i) {
-        if (slot[i].st) (void)hipStreamSynchronize(slot[i].st);
-        if (slot[i].exec) (void)hipGraphExecDestroy(slot[i].exec);
-        if (slot[i].st) srcnn_stream_destroy(slot[i].st);
-        (void)hipFree(slot[i].din); (void)hipFree(slot[i].dout);
-    }
+    for (int i = 0; i < nslots; ++i)
+        if (g.slots[i].st) (void)hipStreamSynchronize(g.slots[i].st);
     if (reg_in) (void)hipHostUnregister(const_cast<float*>(in));
     if (reg_out) (void)hipHostUnregister(out);
     return rc;
