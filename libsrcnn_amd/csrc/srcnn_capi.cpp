@@ -314,7 +314,7 @@ int y_path_rows(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned
                 unsigned r0, unsigned r1, float* d_out, hipStream_t s)
 {
     if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
-    if (dh > 65535u * 4u || dw > 0x7fffffu) return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large", dw, dh);
+    if (dh > 65535u || h > 65535u || dw > 0x7fffffu) return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large (rows are a grid dimension)", dw, dh);
     Workspace& ws = workspace_for(s);
     // rows of layer-2 activations that conv3 touches (clamp-to-edge of the ACTIVATIONS at the true
     // border), and rows of upscaled Y that conv1 touches for those.
