@@ -250,3 +250,22 @@ def test_host_stream_equals_singles(srcnn, use_graph):
     got = srcnn.y_upscale2x_stream(fr, use_graph=use_graph)
     for i in range(7):
         assert_bit_equal(got[i], srcnn.y_upscale2x(fr[i]), "frame %d (graph=%s)" % (i, use_graph))
+
+
+@pytest.mark.parametrize("env", [{"SRCNN_CONV12_VARIANT": "0"}, {"SRCNN_CONV12_VARIANT": "2"}, {"SRCNN_CONV12_VARIANT": "3"},
+                                 {"SRCNN_CONV12": "valu"}])
+def test_alternate_layer12_kernels_bit_exact(env, golden, tmp_path):
+    """The A/B variants of the layer-1+2 kernel (selected by environment at init, hence a subprocess) all
+    reproduce the golden output bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, libsrcnn_amd as S; S.init(0);"
+            "p = np.load(%r); y = p['noise_29x37_in'];"
+            "ok = np.array_equal(S.y_upscale2x(y).view(np.uint32), p['noise_29x37_out'].view(np.uint32));"
+            "y2 = p['smooth_33x65_in'];"
+            "ok = ok and np.array_equal(S.y_upscale2x(y2).view(np.uint32), p['smooth_33x65_out'].view(np.uint32));"
+            "print('BITEXACT' if ok else 'MISMATCH')") % (root, os.path.join(root, "tests", "golden", "y_planes.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert "BITEXACT" in r.stdout, r.stdout + r.stderr
