@@ -317,7 +317,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
                 const float* w2p = W2s + blk * 16 * 64;
                 float a1 = w2p[lane], b1 = myC1[lane];
                 float a2 = w2p[64 + lane], b2 = myC1[64 + lane];
-                if constexpr (PIPE) {
+                if constexpr (!STRICT) {
+                    // FAST: the slab/weight layout (lanes 0-31 channel f, lanes 32-63 channel f+1) is exactly the
+                    // K=2 operand layout of the single-block MFMA, so the pair is one chained FMA update of acc2.
+#pragma unroll
+                    for (int fp = 0; fp < 16; ++fp)
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2p[fp * 64 + lane], myC1[fp * 64 + lane], acc2, 0, 0, 0);
+                } else if constexpr (PIPE) {
                     f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
                     a1 = a2; b1 = b2;
                     a2 = w2p[2 * 64 + lane]; b2 = myC1[2 * 64 + lane];

@@ -269,3 +269,48 @@ def test_alternate_layer12_kernels_bit_exact(env, golden, tmp_path):
             "print('BITEXACT' if ok else 'MISMATCH')") % (root, os.path.join(root, "tests", "golden", "y_planes.npz"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert "BITEXACT" in r.stdout, r.stdout + r.stderr
+
+
+def test_random_shapes_around_tile_edges(srcnn, oracle_lib):
+    """Seeded sweep of input shapes whose 2x outputs straddle the kernels' tile edges (segments of 32 px,
+    tiles of 64x16 / 64x8 rows): every one must equal the oracle bit for bit."""
+    rng = np.random.default_rng(20260)
+    edge_w = [15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 96, 97]
+    edge_h = [3, 4, 5, 7, 8, 9, 15, 16, 17, 23, 24, 25]
+    shapes = [(int(rng.choice(edge_h)), int(rng.choice(edge_w))) for _ in range(14)]
+    shapes += [(int(rng.integers(1, 40)), int(rng.integers(1, 130))) for _ in range(10)]
+    for k, (h, w) in enumerate(shapes):
+        y = synth.plane(h, w, synth.SEED0 + 500 + k, "noise" if k % 2 else "smooth")
+        assert_bit_equal(srcnn.y_upscale2x(y), oracle_lib.y_path(y), "shape %dx%d" % (h, w))
+
+
+def test_concurrent_host_threads_on_own_streams(srcnn, oracle_lib):
+    """Two host threads, each with its own stream (hence its own workspace), interleave calls; results match
+    the oracle and each other run-to-run."""
+    import threading
+    S = srcnn
+    ys = [synth.plane(40, 72, synth.SEED0 + 900 + i, "noise") for i in range(2)]
+    want = [oracle_lib.y_path(y) for y in ys]
+    errs = []
+
+    def worker(i):
+        try:
+            st = S.Stream()
+            din = S.DeviceBuffer.from_numpy(ys[i])
+            dout = S.DeviceBuffer(want[i].nbytes)
+            for _ in range(6):
+                S.check(S.lib().srcnn_y_upscale2x_f32_dev(din.ptr, 72, 40, dout.ptr, st.handle))
+                st.sync()
+                got = dout.to_numpy(np.float32, want[i].shape)
+                if not np.array_equal(got.view(np.uint32), want[i].view(np.uint32)):
+                    errs.append("thread %d mismatch" % i)
+            st.destroy()
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
