@@ -314,3 +314,13 @@ def test_concurrent_host_threads_on_own_streams(srcnn, oracle_lib):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("filt", [0, 1, 2, 3, 4])
+def test_general_y_path_other_filters_and_ratios(srcnn, oracle_lib, filt):
+    """srcnn_y_path_f32 = doSRCNN's Y path for any SRCNNFilterType / ratio (float level, before the u8 merge):
+    non-2x up-scales, a down-scale, and mixed (one axis unchanged) sizes."""
+    y = synth.plane(26, 38, synth.SEED0 + 40 + filt, "smooth")
+    for dw, dh in ((76, 52), (57, 39), (114, 78), (50, 26), (38, 40), (19, 13)):
+        want = oracle_lib.y_path(y, dw, dh, filt)
+        assert_bit_equal(srcnn.y_path(y, dw, dh, filt), want, "filter %d -> %dx%d" % (filt, dw, dh))
