@@ -21,8 +21,9 @@
  *
  * Numerics: mode SRCNN_MODE_STRICT (default) reproduces the reference's float32 results bit
  * for bit (same operation order, separate multiply and add roundings, fp64 where the reference
- * uses double).  SRCNN_MODE_FAST contracts multiply-add pairs to FMA (max |dY| ~2e-4 on the
- * 0..255 scale vs the reference) and is never used unless asked for.
+ * uses double).  The SRCNN_MODE_FAST* tiers contract multiply-add pairs (max |dY| ~2e-4 on the
+ * 0..255 scale vs the reference -- the size of the reference's own fp32 rounding noise) and are never
+ * used unless asked for.
  */
 #ifndef SRCNN_AMD_H
 #define SRCNN_AMD_H
@@ -56,8 +57,10 @@ extern "C" {
 #define SRCNN_FILTER_LANCZOS3 3
 #define SRCNN_FILTER_BSPLINE  4
 
-#define SRCNN_MODE_STRICT 0
-#define SRCNN_MODE_FAST   1
+#define SRCNN_MODE_STRICT   0   /* default: bit-identical to the reference */
+#define SRCNN_MODE_FAST     1   /* fp32 FMA chains (layers 1+2 on the fp32 MFMA, layer 3 v_fma_f32) */
+#define SRCNN_MODE_FAST_F16 2   /* layers 1+2 as split-fp16 GEMMs on the fp16 matrix pipe (3 MFMAs per product
+                                 * term set, fp32 accumulate); same error class as SRCNN_MODE_FAST */
 
 /* ---- lifecycle (the reference has none: it is stateless CPU code; src/libsrcnn.cpp:91-92 are its
  *      only globals).  srcnn_init is idempotent and thread-safe; every compute call self-inits on

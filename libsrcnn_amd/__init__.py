@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsrcnn_amd.so")
 
 SRCNNF_Nearest, SRCNNF_Bilinear, SRCNNF_Bicubic, SRCNNF_Lanczos3, SRCNNF_Bspline = range(5)
-MODE_STRICT, MODE_FAST = 0, 1
+MODE_STRICT, MODE_FAST, MODE_FAST_F16 = 0, 1, 2
 
 # every symbol include/srcnn_amd.h declares (checked by tests/test_abi.py)
 C_ABI_SYMBOLS = [

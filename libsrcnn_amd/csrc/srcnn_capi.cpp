@@ -141,6 +141,7 @@ int ensure_init_locked(int device)
     build_dev_weights(*dw);
     HIP_TRY(upload_weights(*dw));
     HIP_TRY(conv12_mfma_prepare());
+    HIP_TRY(conv12_f16_prepare());
     g.num_cus = prop.multiProcessorCount;
     const char* sel = getenv("SRCNN_CONV12");
     g.conv12_valu = sel && strcmp(sel, "valu") == 0;
@@ -252,7 +253,8 @@ void drain_spans_locked()
 
 void run_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane, int row0, int rows, hipStream_t s)
 {
-    if (g.conv12_valu) launch_conv12(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), s);
+    if (g.mode == SRCNN_MODE_FAST_F16) launch_conv12_f16(Y, W, H, y_row_base, C2, plane, row0, rows, g.num_cus, s);
+    else if (g.conv12_valu) launch_conv12(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), s);
     else launch_conv12_mfma(Y, W, H, y_row_base, C2, plane, row0, rows, strict_mode(), g.num_cus, g.conv12_variant, s);
 }
 
@@ -386,7 +388,7 @@ void srcnn_shutdown(void)
 
 int srcnn_set_mode(int mode)
 {
-    if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST) return fail(SRCNN_E_ARG, "bad mode %d", mode);
+    if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST && mode != SRCNN_MODE_FAST_F16) return fail(SRCNN_E_ARG, "bad mode %d", mode);
     std::lock_guard<std::mutex> lk(g.mu);
     const int prev = g.mode;
     g.mode = mode;

@@ -40,6 +40,9 @@ void launch_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size
 hipError_t conv12_mfma_prepare();
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
                         int out_rows, bool strict, int num_cus, int variant, hipStream_t s);
+hipError_t conv12_f16_prepare();
+void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+                       int out_rows, int num_cus, hipStream_t s);
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
                   int out_row0, int out_rows, bool strict, hipStream_t s);
 void launch_conv1_planes(const float* Y, int W, int H, float* C1, hipStream_t s);

@@ -372,6 +372,206 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
 }
 
 // =============================================================================================
+// FAST tier, layers 1+2 on the fp16 matrix pipe.  Never used in strict mode.
+//
+// Each fp32 operand is split into two fp16 pieces (x = hi + lo exactly to 22 bits; weights are pre-scaled
+// by 2^8 so their low pieces stay out of the fp16 subnormal range) and every product is evaluated as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate, fp32 accumulation), i.e. three
+// MFMAs per 16-deep k-step.  Error vs exact arithmetic is ~1e-6 relative -- the same class as an fp32 FMA
+// evaluation, and like it ~2e-4 away from the reference's own rounding noise.
+//   layer 1 as GEMM  D[ch][px] = sum_k A[ch][k] B[k][px]:  A = weights (rows = 64 channels = 2 blocks),
+//     B = im2col(Y).  A k-step is one row of the 9x9 window: k 0..7 = taps dx 0..7, k 8..15 = taps dx 1..8 with
+//     only dx 8 carrying a weight, so each lane's B fragment is 8 CONTIGUOUS pixels of one tile row.  The
+//     fragment must be 8-byte aligned for ds_read_b64, so the fp16 tile is kept in 4 copies shifted by 0..3
+//     elements; a lane always reads from copy (x + h) & 3.
+//   layer 2: the layer-1 accumulator tile X (rows = channels, column = this lane's pixel) IS the B operand of
+//     the next MFMA (it sums over X's row index): registers 8s..8s+7 converted to fp16 form k-step s with the
+//     permuted k order row = 16s + 8(j>>2) + 4h + (j&3); the W2 fragments are laid out in that order.  No LDS.
+// =============================================================================================
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int F_TW = 64, F_TH = 8, F_LH = F_TH + 8, F_RS = 80;          // tile, staged rows, row stride (halves)
+constexpr int F_CS = 2 * F_LH * F_RS + 16;                              // copy stride in halves: = 32 B mod 128 B, so the
+                                                                        // four copies that neighbouring lanes read
+                                                                        // fall on different banks
+constexpr int F_YC = 4 * F_CS;                                          // [copy]{[hi/lo][row][i]} halves
+constexpr int F_W1 = 9 * 2 * 2 * 64 * 8;                                // [dy][blk][hi/lo][lane][8] halves
+constexpr int F_W2 = 2 * 2 * 2 * 64 * 8;                                // [blk][kstep][hi/lo][lane][8] halves
+constexpr float F_SCALE = 256.f, F_INV = 1.f / 256.f;
+constexpr size_t F_LDS_BYTES = 2 * (size_t)(F_YC + F_W1 + F_W2) + 4 * (64 + 32);
+
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv12_f16(
+    const float* __restrict__ Y, int W, int H, int y_row_base,
+    float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    _Float16* Yc = reinterpret_cast<_Float16*>(lds_raw);
+    _Float16* W1f = Yc + F_YC;
+    _Float16* W2f = W1f + F_W1;
+    float* B1s = reinterpret_cast<float*>(W2f + F_W2);
+    float* B2s = B1s + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
+
+    // ---- weight fragments (once per block) ----
+    for (int e = tid; e < 9 * 2 * 64 * 8; e += 256) {
+        const int j = e & 7, l = (e >> 3) & 63, blk = (e >> 9) & 1, s = e >> 10;
+        const int ch = 32 * blk + (l & 31), h = l >> 5;
+        float w = 0.f;
+        if (h == 0) w = cW.w1t[s * 9 + j][ch];
+        else if (j == 7) w = cW.w1t[s * 9 + 8][ch];
+        _Float16 hi, lo;
+        split_f16(w * F_SCALE, hi, lo);
+        W1f[(((s * 2 + blk) * 2 + 0) * 64 + l) * 8 + j] = hi;
+        W1f[(((s * 2 + blk) * 2 + 1) * 64 + l) * 8 + j] = lo;
+    }
+    for (int e = tid; e < 2 * 2 * 64 * 8; e += 256) {
+        const int j = e & 7, l = (e >> 3) & 63, ks = (e >> 9) & 1, blk = e >> 10;
+        const int m = l & 31, h = l >> 5;
+        const int f = 32 * blk + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        _Float16 hi, lo;
+        split_f16(cW.w2[m][f] * F_SCALE, hi, lo);
+        W2f[(((blk * 2 + ks) * 2 + 0) * 64 + l) * 8 + j] = hi;
+        W2f[(((blk * 2 + ks) * 2 + 1) * 64 + l) * 8 + j] = lo;
+    }
+    if (tid < 64) {
+        const int hf = tid >> 5, r = tid & 31;
+        B1s[tid] = cW.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
+    }
+    if (tid < 32) {
+        const int hf = tid >> 4, r = tid & 15;
+        B2s[tid] = cW.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
+    }
+
+    // The Y values of the NEXT tile are fetched into registers while the current tile is being computed.
+    constexpr int F_PRE = (F_LH * (F_TW + 8) + 255) / 256;
+    float pre[F_PRE];
+    auto fetch = [&](int tile) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * F_TW, ty0 = out_row0 + tyi * F_TH;
+#pragma unroll
+        for (int k = 0; k < F_PRE; ++k) {
+            const int e = tid + 256 * k;
+            const int r = e / (F_TW + 8), c0 = e - r * (F_TW + 8);
+            const int gy = clampi(ty0 + r - 4, 0, H - 1), gx = clampi(tx0 + c0 - 4, 0, W - 1);
+            pre[k] = (e < F_LH * (F_TW + 8)) ? Y[(size_t)(gy - y_row_base) * W + gx] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * F_TW, ty0 = out_row0 + tyi * F_TH;
+        __syncthreads();
+        // ---- fp16 hi/lo tile, 4 shifted copies: copy c, index i holds tile column i + c ----
+#pragma unroll
+        for (int k = 0; k < F_PRE; ++k) {
+            const int e = tid + 256 * k;
+            if (e < F_LH * (F_TW + 8)) {
+                const int r = e / (F_TW + 8), c0 = e - r * (F_TW + 8);
+                _Float16 hi, lo;
+                split_f16(pre[k], hi, lo);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = c0 - c;
+                    if (i >= 0) {
+                        Yc[c * F_CS + (0 * F_LH + r) * F_RS + i] = hi;
+                        Yc[c * F_CS + (1 * F_LH + r) * F_RS + i] = lo;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+
+#pragma unroll 1
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int sg = wv * 4 + sidx;
+            const int trow = sg >> 1, seg = sg & 1;
+            const int q = seg * 32 + col + half, cpy = q & 3, bi = q - cpy;
+            const _Float16* yh = Yc + cpy * F_CS + (0 * F_LH + trow) * F_RS + bi;
+            const _Float16* yl = Yc + cpy * F_CS + (1 * F_LH + trow) * F_RS + bi;
+
+            f32x16 acc0 = {}, acc1 = {};
+            // k-step fragments are fetched one step ahead of the MFMAs that consume them
+            auto ld_b = [&](int s, h8& bh, h8& bl) {
+                // two 8-byte reads per fragment, kept apart by a compiler barrier: merged into one ds_read_b128
+                // they would be misaligned for half of the lanes and replay
+                const h4 bh0 = *reinterpret_cast<const h4*>(yh + s * F_RS), bl0 = *reinterpret_cast<const h4*>(yl + s * F_RS);
+                asm volatile("" ::: "memory");
+                const h4 bh1 = *reinterpret_cast<const h4*>(yh + s * F_RS + 4), bl1 = *reinterpret_cast<const h4*>(yl + s * F_RS + 4);
+                bh = __builtin_shufflevector(bh0, bh1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bl = __builtin_shufflevector(bl0, bl1, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            auto ld_a = [&](int s, int blk, int hl) {
+                return *reinterpret_cast<const h8*>(W1f + (((s * 2 + blk) * 2 + hl) * 64 + lane) * 8);
+            };
+            h8 bh, bl, a0h, a0l, a1h, a1l;
+            ld_b(0, bh, bl);
+            a0h = ld_a(0, 0, 0); a0l = ld_a(0, 0, 1); a1h = ld_a(0, 1, 0); a1l = ld_a(0, 1, 1);
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                h8 nbh = bh, nbl = bl, n0h = a0h, n0l = a0l, n1h = a1h, n1l = a1l;
+                if (s + 1 < 9) {
+                    ld_b(s + 1, nbh, nbl);
+                    n0h = ld_a(s + 1, 0, 0); n0l = ld_a(s + 1, 0, 1); n1h = ld_a(s + 1, 1, 0); n1l = ld_a(s + 1, 1, 1);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                bh = nbh; bl = nbl; a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+            }
+            // ---- bias + ReLU (undo the weight scale first: exact power of two) ----
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0[r] = fmaxf(acc0[r] * F_INV + B1s[half * 32 + r], 0.f);
+                acc1[r] = fmaxf(acc1[r] * F_INV + B1s[half * 32 + 16 + r], 0.f);
+            }
+            // ---- layer 2: the accumulator tiles are the B operands ----
+            f32x16 acc2 = {};
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    h8 xh, xl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = blk ? acc1[8 * ks + j] : acc0[8 * ks + j];
+                        _Float16 hi, lo;
+                        split_f16(x, hi, lo);
+                        xh[j] = hi; xl[j] = lo;
+                    }
+                    const h8 ah = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 0) * 64 + lane) * 8);
+                    const h8 al = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 1) * 64 + lane) * 8);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc2, 0, 0, 0);
+                }
+            const int row = ty0 + trow, x = tx0 + seg * 32 + col;
+            if (row < out_row0 + out_rows && row < H && x < W) {
+                float* dst = C2 + (size_t)(row - out_row0) * W + x;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 8 * (r >> 2) + (r & 3);
+                    dst[(size_t)(m + 4 * half) * plane_stride] = fmaxf(acc2[r] * F_INV + B2s[half * 16 + r], 0.f);
+                }
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // conv3: 5x5x32->1 + bias + clamp[0,255].  Per channel the reference sums fp32 products in an
 // fp64 accumulator (25 taps, row-major over the window), then folds it into an fp32 running sum:
 //     v_pk_mul_f32 (2 products) ; v_cvt_f64_f32 ; v_add_f64      -- 2.5 VALU instructions per MAC.
@@ -637,6 +837,23 @@ hipError_t conv12_mfma_prepare()
     PREP(4, 1, 3) PREP(8, 0, 4) PREP(4, 0, 3) PREP(8, 1, 2)
 #undef PREP
     return hipSuccess;
+}
+
+hipError_t conv12_f16_prepare()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_f16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)F_LDS_BYTES);
+}
+
+void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+                       int out_rows, int num_cus, hipStream_t s)
+{
+    if (out_rows <= 0) return;
+    const int tiles_x = (int)cdiv(W, F_TW), tiles_y = (int)cdiv(out_rows, F_TH);
+    const int ntiles = tiles_x * tiles_y;
+    const int grid = std::min(ntiles, 2 * num_cus);
+    hipLaunchKernelGGL(k_conv12_f16, dim3(grid), dim3(256), F_LDS_BYTES, s, Y, W, H, y_row_base, C2, plane_stride,
+                       out_row0, out_rows, tiles_x, ntiles);
 }
 
 template <int NW, int PIPE, int WPS>

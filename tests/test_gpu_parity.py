@@ -166,17 +166,25 @@ def test_4k_to_8k_constant_and_checksum(srcnn, golden):
     assert np.all(out.view(np.uint32) == golden.known["constant_planes"]["128.0"]["bits"])
 
 
-def test_fast_mode_within_documented_bound(srcnn, oracle_lib):
-    y = synth.plane(64, 96, synth.SEED0 + 9, "noise")
-    want = oracle_lib.y_path(y)
-    prev = srcnn.set_mode(srcnn.MODE_FAST)
-    try:
-        got = srcnn.y_upscale2x(y)
-    finally:
-        srcnn.set_mode(prev)
-    err = float(np.max(np.abs(got.astype(np.float64) - want)))
-    assert err <= TOL_FAST, err
-    assert_bit_equal(srcnn.y_upscale2x(y), want, "strict again after fast")
+@pytest.mark.parametrize("mode_name", ["MODE_FAST", "MODE_FAST_F16"])
+def test_fast_modes_within_documented_bound(srcnn, oracle_lib, mode_name):
+    """The non-parity tiers (fp32 FMA chains; split-fp16 GEMMs on the matrix pipe) stay within the documented
+    bound of the reference (measured max ~3e-4 = the reference's own fp32 rounding noise), on both data kinds and
+    on shapes that exercise the tile edges; strict mode is unaffected afterwards."""
+    worst = 0.0
+    for shape, kind in (((64, 96), "noise"), ((37, 131), "smooth"), ((9, 70), "noise")):
+        y = synth.plane(shape[0], shape[1], synth.SEED0 + 9, kind)
+        want = oracle_lib.y_path(y)
+        prev = srcnn.set_mode(getattr(srcnn, mode_name))
+        try:
+            got = srcnn.y_upscale2x(y)
+        finally:
+            srcnn.set_mode(prev)
+        err = float(np.max(np.abs(got.astype(np.float64) - want)))
+        worst = max(worst, err)
+        assert err <= TOL_FAST, (mode_name, shape, err)
+        assert_bit_equal(srcnn.y_upscale2x(y), want, "strict again after %s" % mode_name)
+    assert worst > 0.0      # these tiers really are a different evaluation order
 
 
 def test_error_codes(srcnn):

@@ -25,7 +25,7 @@ def main():
         dc2 = S.DeviceBuffer(32 * H * W * 4)
         dout = S.DeviceBuffer(H * W * 4)
         L = S.lib()
-        for mode in (S.MODE_STRICT, S.MODE_FAST):
+        for mode in (S.MODE_STRICT, S.MODE_FAST, S.MODE_FAST_F16):
             S.set_mode(mode)
             t_rs = timeit(lambda: S.check(L.srcnn_resample_f32_dev(din.ptr, w, h, W, H, 2, dup.ptr, None)))
             t_c12 = timeit(lambda: S.check(L.srcnn_conv12_f32_dev(dup.ptr, W, H, dc2.ptr, None)))
@@ -33,7 +33,7 @@ def main():
             t_all = timeit(lambda: S.check(L.srcnn_y_upscale2x_f32_dev(din.ptr, w, h, dout.ptr, None)))
             mp = H * W / 1e6
             print("%dx%d->%dx%d mode=%s: resample %.3f ms  conv12 %.3f ms  conv3 %.3f ms  | whole %.3f ms = %.1f MPix/s  (%.2f TFLOP/s algorithmic)"
-                  % (w, h, W, H, "strict" if mode == 0 else "fast", t_rs, t_c12, t_c3, t_all, mp / t_all * 1e3, 16064 * mp * 1e6 / (t_all * 1e-3) / 1e12))
+                  % (w, h, W, H, ("strict", "fast", "fast_f16")[mode], t_rs, t_c12, t_c3, t_all, mp / t_all * 1e3, 16064 * mp * 1e6 / (t_all * 1e-3) / 1e12))
         S.set_mode(S.MODE_STRICT)
         for b in (din, dup, dc2, dout): b.free()
 
