@@ -285,6 +285,20 @@ def main():
             "max_abs_dY_vs_cpu_ref": None,
             "device": S.device_name(),
         }
+        if world == 1:
+            # non-parity tiers, same frames, 2 steps each: reported beside the headline, never as `value`
+            tiers = {}
+            for mode, name in ((S.MODE_FAST, "fast_fp32_fma"), (S.MODE_FAST_F16, "fast_split_fp16_mfma")):
+                S.set_mode(mode)
+                step(); S.sync()
+                t0f = time.perf_counter()
+                for _ in range(2):
+                    step()
+                S.sync()
+                tiers[name] = {"MPix/s": round(F * n_out / 1e6 / ((time.perf_counter() - t0f) / 2), 1),
+                               "max_abs_dY_vs_reference": "~3e-4 (tests/test_gpu_parity.py: <= 1e-3)"}
+            S.set_mode(S.MODE_STRICT)
+            out["non_parity_tiers"] = tiers
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["max_abs_dY_vs_cpu_ref"] = cpu_baseline(S)
