@@ -13,9 +13,9 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { MFMA_ONLY, ADDS_ONLY, BOTH, BOTH_ADDS8, BOTH_ADDS12, MFMA16_BOTH, SCALAR_ONLY, BOTH_SCALAR, NV };
+enum { MFMA_ONLY, ADDS_ONLY, BOTH, BOTH_ADDS8, BOTH_ADDS12, MFMA16_BOTH, SCALAR_ONLY, BOTH_SCALAR, F64_ONLY, BOTH_F64, CVT_ONLY, BOTH_CVT, NV };
 const char* kN[NV] = {"mfma32x32x1_2b only", "16 pk_add only", "mfma32 + 16 pk_add", "mfma32 + 8 pk_add", "mfma32 + 12 pk_add",
-                      "mfma16x16x1_4b + 8 pk_add", "32 v_add_f32 only", "mfma32 + 32 v_add_f32"};
+                      "mfma16x16x1_4b + 8 pk_add", "32 v_add_f32 only", "mfma32 + 32 v_add_f32", "16 v_add_f64 only", "mfma32 + 16 v_add_f64", "16 v_cvt_f64_f32 only", "mfma32 + 16 v_cvt_f64_f32"};
 
 template <int V>
 __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* clk, int iters, float a0, float b0)
@@ -24,6 +24,8 @@ __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* clk,
     float a = a0 + lane * 1e-3f, b = b0 + lane * 2e-3f;
     const f32x32 zero = {};
     f32x32 acc = zero, d_cur = zero;
+    double dacc[16]; double dinc = 1e-9 * lane;
+    for (int i = 0; i < 16; ++i) dacc[i] = i;
     for (int i = 0; i < 32; ++i) d_cur[i] = lane * 1e-6f * i;
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
@@ -89,11 +91,31 @@ __global__ __launch_bounds__(256, 2) void k(float* out, unsigned long long* clk,
 #pragma unroll
             for (int i = 0; i < 32; ++i) { float x = acc[i]; asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(d[i])); acc[i] = x; }
             __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (V == F64_ONLY || V == BOTH_F64) {
+            // 16 independent fp64 adds on registers that the MFMA never touches
+            if constexpr (V == BOTH_F64) {
+                f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, zero, 0, 0, 0); PIN(d);
+                __builtin_amdgcn_sched_barrier(0);
+                d_cur = d;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(dacc[i]) : "v"(dinc));
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (V == CVT_ONLY || V == BOTH_CVT) {
+            if constexpr (V == BOTH_CVT) {
+                f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, zero, 0, 0, 0); PIN(d);
+                __builtin_amdgcn_sched_barrier(0);
+                d_cur = d;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dacc[i]) : "v"(a));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
     for (int i = 0; i < 32; ++i) s += acc[i] + d_cur[i];
+    for (int i = 0; i < 16; ++i) s += (float)dacc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
@@ -102,7 +124,7 @@ template <int V>
 void run(int bpc, int cus, float* d_out, unsigned long long* d_clk)
 {
     const int iters = 100000, grid = cus * bpc;
-    const int steps = (V == MFMA_ONLY || V == ADDS_ONLY || V == SCALAR_ONLY) ? 1 : 2;
+    const int steps = (V == BOTH || V == BOTH_ADDS8 || V == BOTH_ADDS12 || V == MFMA16_BOTH || V == BOTH_SCALAR) ? 2 : 1;
     hipLaunchKernelGGL(k<V>, dim3(grid), dim3(256), 0, 0, d_out, d_clk, 1000, 1.0f, 0.5f);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -136,6 +158,10 @@ int main()
         run<MFMA16_BOTH>(bpc, cus, d_out, d_clk);
         run<SCALAR_ONLY>(bpc, cus, d_out, d_clk);
         run<BOTH_SCALAR>(bpc, cus, d_out, d_clk);
+        run<F64_ONLY>(bpc, cus, d_out, d_clk);
+        run<BOTH_F64>(bpc, cus, d_out, d_clk);
+        run<CVT_ONLY>(bpc, cus, d_out, d_clk);
+        run<BOTH_CVT>(bpc, cus, d_out, d_clk);
         printf("\n");
     }
     return 0;
