@@ -22,9 +22,15 @@ def one(pattern):
 
 
 def short(name):
-    for key in ("k_conv12_mfma", "k_conv12", "k_conv3", "k_resample_rows", "k_resample_cols", "k_rgb_split", "k_ycc_merge"):
+    tier = ""
+    if "<true" in name:
+        tier = " [strict]"
+    elif "<false" in name:
+        tier = " [fast tier]"
+    for key in ("k_conv12_f16", "k_conv12_mfma", "k_conv12", "k_conv3", "k_resample_rows", "k_resample_cols", "k_rgb_split",
+                "k_ycc_merge"):
         if key in name:
-            return key
+            return key + (" [fast tier]" if key == "k_conv12_f16" else tier)
     return name[:40]
 
 
@@ -54,7 +60,7 @@ if pmc:
     lines.append("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
     for k, v in pmc.items():
         lines.append("| %s | " % k + " | ".join("%.6g" % v.get(c, float("nan")) for c in cols) + " |")
-    k12 = pmc.get("k_conv12_mfma") or pmc.get("k_conv12")
+    k12 = pmc.get("k_conv12_mfma [strict]")
     if k12 and "FETCH_SIZE" in k12 and "WRITE_SIZE" in k12:
         n_out = 7680 * 4320
         fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024
