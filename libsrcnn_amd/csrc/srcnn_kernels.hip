@@ -1,24 +1,26 @@
 // srcnn_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the SRCNN Y path.
 //
 // Reference behaviour reproduced (rageworx/libsrcnn, paths relative to its tree):
-//   resample_*      FRAWResizeEngine::verticalFilter / horizontalFilter  src/frawscale.cpp:288-385
-//   conv12          64 x convolution99 + 32 x convolution11              src/libsrcnn.cpp:350-447
-//   conv3           convolution55                                        src/libsrcnn.cpp:449-529
-//   conv1 / conv2   the same two layers unfused (stage-level parity)     src/libsrcnn.cpp:350-447
-//   rgb_split / ycc_merge  colour shell                                  src/libsrcnn.cpp:233-308,889-905
+//   k_resample_cols/rows  FRAWResizeEngine::verticalFilter / horizontalFilter   src/frawscale.cpp:288-385
+//   k_conv12_mfma         64 x convolution99 + 32 x convolution11  (production)  src/libsrcnn.cpp:350-447
+//   k_conv12              the same on the VALU only (A/B alternative, SRCNN_CONV12=valu)
+//   k_conv12_f16          the same as split-fp16 GEMMs (non-parity tier SRCNN_MODE_FAST_F16)
+//   k_conv3               convolution55                                          src/libsrcnn.cpp:449-529
+//   k_conv1/2_planes      the two layers unfused, 64 / 32 planes in HBM (stage-level parity entry points)
+//   k_rgb_split / k_ycc_merge  colour shell                                      src/libsrcnn.cpp:233-308,889-905
 //
-// STRICT kernels keep the reference's evaluation order and roundings exactly: one rounded fp32
-// product then one rounded fp32 add per tap (no FMA; this TU is built with -ffp-contract=off and
-// the pragma below), taps in the reference's loop order, fp64 where the reference uses double.
-// FAST kernels (template parameter) contract each pair to one FMA.
+// STRICT kernels keep the reference's evaluation order and roundings exactly: one rounded fp32 product then
+// one rounded fp32 add per tap (no FMA; this TU is built with -ffp-contract=off and the pragma below), taps in
+// the reference's loop order, fp64 where the reference uses double.  The non-parity tiers are template
+// parameters / separate kernels and are never selected unless srcnn_set_mode asks for them.
 //
-// Data layout in HBM: every image is planar float32, row-major; activation stacks are
-// [channel][row][col] with a caller-given plane stride.  Weights live in __constant__ memory and
-// reach the VALU as SGPR operands (wave-uniform addresses -> s_load), re-laid out so that the
-// values one unrolled inner loop needs are contiguous:
+// Data layout in HBM: every image is planar float32, row-major; activation stacks are [channel][row][col]
+// with a caller-given plane stride.  Weights live in __constant__ memory, re-laid out once on the host:
 //   w1t[tap][k]   (tap = 9*row_off + col_off)   <- weights_conv1_data[k][row_off][col_off]
 //   w2 [m][f]                                    <- weights_conv2_data[m][f]
 //   w3 [m][dy][dx]                               <- weights_conv3_data[m][dx][dy]   (transposed!)
+// VALU kernels read them as SGPR operands (wave-uniform addresses -> s_load); the MFMA kernels re-stage
+// them into LDS per block in operand (lane) order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(256) void k_resample_rows(   // horizontal pass: [r
 }
 
 // =============================================================================================
-// conv12: 9x9x1->64 + ReLU, then 1x1x64->32 + ReLU, fused; the 64 intermediate planes of the
+// conv12, VALU-only alternative (SRCNN_CONV12=valu; the production kernel is k_conv12_mfma below):
+// 9x9x1->64 + ReLU, then 1x1x64->32 + ReLU, fused; the 64 intermediate planes of the
 // reference never exist.  Lane = PX output pixels of one row (x = tile_x + lane + 64*p); all 64
 // layer-1 accumulators of a pixel live in VGPRs, weights arrive as SGPRs.  The Y tile (+4 halo,
 // clamp-to-edge at the true image border) is staged once in LDS.
@@ -163,15 +166,16 @@ __global__ __launch_bounds__(256) void k_conv12(
 }
 
 // =============================================================================================
-// conv12 on BOTH pipes of the SIMD (the production layer-1+2 kernel).
+// conv12 with exact products from the matrix instruction (the production layer-1+2 kernel).
 //
 // Strict mode may not fuse the multiply into the add, so on the VALU every MAC costs two
 // instructions.  gfx950's K=1 multi-block MFMA computes D = A (x) B + C per block with one
 // rounding (an fmaf); with C = 0 that is exactly the correctly rounded fp32 PRODUCT.  So the
 // matrix pipe produces the 64-channel x 32-pixel outer product of one tap
 //     D[k][px] = round(w1[k][tap] * Y[px + tap])          (v_mfma_f32_32x32x1_2b_f32, C = 0)
-// while the VALU only accumulates  acc[k][px] += D[k][px]  (16 v_pk_add_f32), in the reference's
-// tap order.  Elementwise adds do not care about the MFMA register layout; it matters only for the
+// and the VALU only accumulates  acc[k][px] += D[k][px]  (16 v_pk_add_f32), in the reference's
+// tap order.  (Measured: the fp32 MFMA does not overlap with VALU work on gfx950 -- it is simply the cheapest way
+// to get 2048 correctly rounded products: 64 cycles, two one-register operands, no SGPR weight traffic.)  Elementwise adds do not care about the MFMA register layout; it matters only for the
 // bias/ReLU epilogue and the hand-off to layer 2:
 //     block b = reg/16 (lanes 32b..32b+31 feed A/B of block b), row = 8*((reg%16)/4) + 4*(lane/32) + reg%4,
 //     col = lane%32.                        A_b[row] <- lane 32b+row,   B_b[col] <- lane 32b+col
