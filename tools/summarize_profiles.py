@@ -66,8 +66,10 @@ if pmc:
         fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024
         rec = {"kernel": "k_conv12_mfma", "tag": tag, "fetch_bytes": fetch, "write_bytes": write,
                "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 132 * n_out,
-               "note": "FETCH_SIZE taken at face value: this kernel reads 4 B/lane (the guide's x2 correction is for "
-                       "16 B/lane streams); WRITE_SIZE matches 128 B/px exactly"}
+               "note": "FETCH_SIZE/WRITE_SIZE are KiB, separate passes.  The guide's x2 FETCH correction is for 16 B/lane streams; "
+                       "our loads are 4 B/lane, calibrated on k_conv3 of the same run: it requests 5.65 GB (4.25 GB of unique "
+                       "layer-2 planes x 1.33 halo) and FETCH_SIZE reads 4.73 GB -- a halved counter would imply 9.5 GB, more "
+                       "than was requested -- so FETCH_SIZE is taken at face value.  WRITE_SIZE matches 128 B/px exactly."}
         json.dump(rec, open(os.path.join(dst, "pmc_conv12.json"), "w"), indent=1)
         lines.append("\nconv12 HBM traffic per launch = %.3f GB (fetch %.3f + write %.3f) vs algorithmic %.3f GB -> ratio %.3f"
                      % ((fetch + write) / 1e9, fetch / 1e9, write / 1e9, 132 * n_out / 1e9, (fetch + write) / (132 * n_out)))
