@@ -52,7 +52,8 @@ struct DeviceTable {
     int* taps = nullptr;
     double* weight = nullptr;
     int stride = 0;
-    DevAxisTable view() const { return DevAxisTable{first, taps, weight, stride}; }
+    int max_taps = 0;
+    DevAxisTable view() const { return DevAxisTable{first, taps, weight, stride, max_taps}; }
 };
 
 struct Workspace {          // scratch of one stream; grow-only
@@ -186,6 +187,7 @@ int get_table(int filter, unsigned dst_len, unsigned src_len, DeviceTable& out)
     const AxisTable t = build_axis_table(filter, dst_len, src_len);
     DeviceTable d;
     d.stride = t.stride;
+    d.max_taps = t.max_taps;
     HIP_TRY(hipMalloc((void**)&d.first, sizeof(int) * dst_len));
     HIP_TRY(hipMalloc((void**)&d.taps, sizeof(int) * dst_len));
     HIP_TRY(hipMalloc((void**)&d.weight, sizeof(double) * t.weight.size()));

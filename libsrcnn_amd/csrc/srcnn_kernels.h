@@ -27,6 +27,7 @@ struct DevAxisTable {          // device pointers into one uploaded AxisTable
     const int* taps;
     const double* weight;
     int stride;
+    int max_taps;
 };
 
 hipError_t upload_weights(const DevWeights& w);

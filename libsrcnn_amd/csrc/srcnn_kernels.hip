@@ -85,6 +85,33 @@ __global__ __launch_bounds__(256) void k_resample_rows(   // horizontal pass: [r
     dst[(size_t)y * dst_w + x] = (float)acc;
 }
 
+// Same pass for tables with at most RS_MAXT taps (every up-scale with the five filters): a thread keeps the
+// weights of its output column in registers and walks RS_RPT rows, so the per-column table is read once per
+// RS_RPT rows instead of once per pixel (the table, not the image, was the dominant traffic).
+constexpr int RS_MAXT = 8, RS_RPT = 8;
+__global__ __launch_bounds__(256) void k_resample_rows_reg(
+    const float* __restrict__ src, int src_w, float* __restrict__ dst, int dst_w, int rows,
+    const int* __restrict__ first, const int* __restrict__ taps, const double* __restrict__ wt, int stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y0 = blockIdx.y * RS_RPT;
+    if (x >= dst_w) return;
+    const int s0 = first[x], n = taps[x];
+    const double* wr = wt + (size_t)x * stride;
+    double w[RS_MAXT];
+#pragma unroll
+    for (int t = 0; t < RS_MAXT; ++t) w[t] = t < n ? wr[t] : 0.0;
+    const int y1 = min(y0 + RS_RPT, rows);
+    for (int y = y0; y < y1; ++y) {
+        const float* in = src + (size_t)y * src_w + s0;
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < RS_MAXT; ++t)
+            if (t < n) acc = acc + w[t] * (double)in[t];     // same taps, same order as the generic kernel
+        dst[(size_t)y * dst_w + x] = (float)acc;
+    }
+}
+
 // =============================================================================================
 // conv12, VALU-only alternative (SRCNN_CONV12=valu; the production kernel is k_conv12_mfma below):
 // 9x9x1->64 + ReLU, then 1x1x64->32 + ReLU, fused; the 64 intermediate planes of the
@@ -802,6 +829,12 @@ void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, in
                           hipStream_t s)
 {
     if (rows <= 0) return;
+    if (t.max_taps <= RS_MAXT) {
+        dim3 grid(cdiv(dst_w, 256), cdiv(rows, RS_RPT));
+        hipLaunchKernelGGL(k_resample_rows_reg, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
+                           t.weight, t.stride);
+        return;
+    }
     dim3 grid(cdiv(dst_w, 256), rows);
     hipLaunchKernelGGL(k_resample_rows, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
                        t.weight, t.stride);
