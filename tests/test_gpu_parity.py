@@ -332,3 +332,24 @@ def test_general_y_path_other_filters_and_ratios(srcnn, oracle_lib, filt):
     for dw, dh in ((76, 52), (57, 39), (114, 78), (50, 26), (38, 40), (19, 13)):
         want = oracle_lib.y_path(y, dw, dh, filt)
         assert_bit_equal(srcnn.y_path(y, dw, dh, filt), want, "filter %d -> %dx%d" % (filt, dw, dh))
+
+
+def test_special_values_match_reference_semantics(srcnn, oracle_lib):
+    """Denormals, signed zeros, huge values, infinities and NaNs go through the strict kernels exactly as they go
+    through the reference's scalar code (products on the matrix instruction keep fp32 denormals; ReLU maps NaN
+    to 0 like `(t >= 0) ? t : 0`)."""
+    y = synth.plane(24, 40, synth.SEED0 + 77, "noise")
+    y[2, 3] = 1e-40          # fp32 denormal
+    y[2, 4] = -1e-42
+    y[5, 7] = -0.0
+    y[9, 9] = 3e30
+    y[9, 30] = -3e30
+    y[15, 20] = np.inf
+    y[18, 5] = -np.inf
+    y[21, 33] = np.nan
+    want = oracle_lib.y_path(y)
+    got = srcnn.y_upscale2x(y)
+    # NaN payloads are not part of the contract: compare NaN-ness, and bits everywhere else
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(got.view(np.uint32)[ok], want.view(np.uint32)[ok])
