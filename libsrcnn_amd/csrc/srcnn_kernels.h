@@ -36,13 +36,13 @@ void launch_resample_cols(const float* src, int w, int src_row_base, float* dst,
                           const DevAxisTable& t, hipStream_t s);
 void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, int rows, const DevAxisTable& t,
                           hipStream_t s);
-void launch_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                    int out_rows, bool strict, hipStream_t s);
 hipError_t conv12_mfma_prepare();
-void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                         int out_rows, bool strict, int num_cus, int variant, hipStream_t s);
 hipError_t conv12_f16_prepare();
-void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                        int out_rows, int num_cus, hipStream_t s);
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
                   int out_row0, int out_rows, bool strict, hipStream_t s);

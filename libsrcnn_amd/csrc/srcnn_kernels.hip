@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_resample_rows_reg(
 // =============================================================================================
 template <int PX, bool STRICT>
 __global__ __launch_bounds__(256) void k_conv12(
-    const float* __restrict__ Y, int W, int H, int y_row_base,        // Y holds rows [y_row_base, ...)
+    const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,   // Y holds rows [y_row_base, +y_rows)
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows)  // writes rows [out_row0, +out_rows)
 {
     constexpr int TW = 64 * PX;          // tile width  (one wave spans it)
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_conv12(
     const int ty0 = out_row0 + blockIdx.y * TH;
     for (int e = threadIdx.x; e < (TH + 8) * LW; e += 256) {
         const int r = e / LW, c = e - r * LW;
-        const int gy = clampi(ty0 + r - 4, 0, H - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
+        const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
         tile[e] = Y[(size_t)(gy - y_row_base) * W + gx];
     }
     __syncthreads();
@@ -231,7 +231,7 @@ constexpr int m_lds_floats(int nw) { return M_W1 + M_W2 + M_B1 + M_B2 + m_yt(nw)
 // MFMA and other waves fill the gap (fewer registers -> more waves per SIMD).
 template <bool STRICT, int NW, int PIPE, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
-    const float* __restrict__ Y, int W, int H, int y_row_base,
+    const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
 {
     constexpr int NT = 64 * NW, TH = m_th(NW), YT = m_yt(NW);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
         __syncthreads();
         for (int e = tid; e < YT; e += NT) {
             const int r = e / M_LW, c = e - r * M_LW;
-            const int gy = clampi(ty0 + r - 4, 0, H - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
+            const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
             Yt[e] = Y[(size_t)(gy - y_row_base) * W + gx];
         }
         __syncthreads();
@@ -439,7 +439,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo)
 }
 
 __global__ __launch_bounds__(256, 2) void k_conv12_f16(
-    const float* __restrict__ Y, int W, int H, int y_row_base,
+    const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_f16(
         for (int k = 0; k < F_PRE; ++k) {
             const int e = tid + 256 * k;
             const int r = e / (F_TW + 8), c0 = e - r * (F_TW + 8);
-            const int gy = clampi(ty0 + r - 4, 0, H - 1), gx = clampi(tx0 + c0 - 4, 0, W - 1);
+            const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c0 - 4, 0, W - 1);
             pre[k] = (e < F_LH * (F_TW + 8)) ? Y[(size_t)(gy - y_row_base) * W + gx] : 0.f;
         }
     };
@@ -840,17 +840,17 @@ void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, in
                        t.weight, t.stride);
 }
 
-void launch_conv12(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                    int out_rows, bool strict, hipStream_t s)
 {
     if (out_rows <= 0) return;
     constexpr int PX = 2;
     dim3 grid(cdiv(W, 64 * PX), cdiv(out_rows, 4));
     if (strict)
-        hipLaunchKernelGGL((k_conv12<PX, true>), grid, dim3(256), 0, s, Y, W, H, y_row_base, C2, plane_stride,
+        hipLaunchKernelGGL((k_conv12<PX, true>), grid, dim3(256), 0, s, Y, W, H, y_row_base, y_rows, C2, plane_stride,
                            out_row0, out_rows);
     else
-        hipLaunchKernelGGL((k_conv12<PX, false>), grid, dim3(256), 0, s, Y, W, H, y_row_base, C2, plane_stride,
+        hipLaunchKernelGGL((k_conv12<PX, false>), grid, dim3(256), 0, s, Y, W, H, y_row_base, y_rows, C2, plane_stride,
                            out_row0, out_rows);
 }
 
@@ -882,19 +882,19 @@ hipError_t conv12_f16_prepare()
                                (int)F_LDS_BYTES);
 }
 
-void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                        int out_rows, int num_cus, hipStream_t s)
 {
     if (out_rows <= 0) return;
     const int tiles_x = (int)cdiv(W, F_TW), tiles_y = (int)cdiv(out_rows, F_TH);
     const int ntiles = tiles_x * tiles_y;
     const int grid = std::min(ntiles, 2 * num_cus);
-    hipLaunchKernelGGL(k_conv12_f16, dim3(grid), dim3(256), F_LDS_BYTES, s, Y, W, H, y_row_base, C2, plane_stride,
+    hipLaunchKernelGGL(k_conv12_f16, dim3(grid), dim3(256), F_LDS_BYTES, s, Y, W, H, y_row_base, y_rows, C2, plane_stride,
                        out_row0, out_rows, tiles_x, ntiles);
 }
 
 template <int NW, int PIPE, int WPS>
-static void launch_v(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                      int out_rows, bool strict, int num_cus, int blocks_per_cu, hipStream_t s)
 {
     const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, m_th(NW));
@@ -902,22 +902,22 @@ static void launch_v(const float* Y, int W, int H, int y_row_base, float* C2, si
     const int grid = std::min(ntiles, blocks_per_cu * num_cus);     // resident blocks only; tile loop inside
     const size_t lds = sizeof(float) * m_lds_floats(NW);
     if (strict)
-        hipLaunchKernelGGL((k_conv12_mfma<true, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base,
+        hipLaunchKernelGGL((k_conv12_mfma<true, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, y_rows,
                            C2, plane_stride, out_row0, out_rows, tiles_x, ntiles);
     else
-        hipLaunchKernelGGL((k_conv12_mfma<false, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base,
+        hipLaunchKernelGGL((k_conv12_mfma<false, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, y_rows,
                            C2, plane_stride, out_row0, out_rows, tiles_x, ntiles);
 }
 
-void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, float* C2, size_t plane_stride, int out_row0,
+void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                         int out_rows, bool strict, int num_cus, int variant, hipStream_t s)
 {
     if (out_rows <= 0) return;
     switch (variant) {
-    case 0: launch_v<4, 1, 3>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
-    default: launch_v<8, 0, 4>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 2, s); break;
-    case 2: launch_v<4, 0, 3>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
-    case 3: launch_v<8, 1, 2>(Y, W, H, y_row_base, C2, plane_stride, out_row0, out_rows, strict, num_cus, 1, s); break;
+    case 0: launch_v<4, 1, 3>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
+    default: launch_v<8, 0, 4>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 2, s); break;
+    case 2: launch_v<4, 0, 3>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
+    case 3: launch_v<8, 1, 2>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 1, s); break;
     }
 }
 

@@ -353,3 +353,23 @@ def test_special_values_match_reference_semantics(srcnn, oracle_lib):
     assert np.array_equal(np.isnan(got), np.isnan(want))
     ok = ~np.isnan(want)
     assert np.array_equal(got.view(np.uint32)[ok], want.view(np.uint32)[ok])
+
+
+def test_processsrcnn_large_image_pipelined_path(srcnn, oracle_lib):
+    """Images whose output exceeds 8 MB take the banded, double-staged ProcessSRCNN path (page-locked staging,
+    per-band D2H on a copy stream, host fan-out thread); RGB and RGBA results must still equal the oracle's
+    byte for byte, including the conv-Y plane."""
+    rng = np.random.default_rng(5)
+    base = synth.plane(640, 1100, synth.SEED0 + 321, "smooth")
+    for d in (3, 4):
+        img = np.empty((640, 1100, d), np.uint8)
+        for k in range(d):
+            img[..., k] = np.clip(base * (0.6 + 0.2 * k) + rng.integers(0, 30, base.shape), 0, 255).astype(np.uint8)
+        want_rgb, want_conv = oracle_lib.process(img, 2.0)
+        srcnn.ConfigureFilterSRCNN(srcnn.SRCNNF_Bicubic, False)
+        rc, out, conv = srcnn.ProcessSRCNN(img, 1100, 640, d, 2.0)
+        assert rc == 0
+        assert np.array_equal(out.reshape(want_rgb.shape), want_rgb), "d=%d" % d
+        assert np.array_equal(conv.reshape(want_conv.shape), want_conv), "d=%d conv" % d
+        rc, out2, none = srcnn.ProcessSRCNN(img, 1100, 640, d, 2.0, want_conv=False)
+        assert rc == 0 and none is None and np.array_equal(out2, out)

@@ -7,6 +7,7 @@
 //
 // Writes <source>_resized.ppm (or the given output) and <source>_convolution.pgm (the truncated SRCNN Y
 // plane), and prints the wall time of the ProcessSRCNN call like the reference ("Test Ok, took N ms.").
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -92,12 +93,14 @@ int main(int argc, char** argv)
 {
     float scale = 2.0f;                      // the reference's default image_multiply (src/test.cpp:288)
     bool step = false;
+    int repeat = 1;                          // --repeat=N: call ProcessSRCNN N times, report every wall time
     SRCNNFilterType filt = SRCNNF_Bicubic;
     std::string src, dst;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a.rfind("--scale=", 0) == 0) { const float v = (float)atof(a.c_str() + 8); if (v > 0.f) scale = v; }
         else if (a.rfind("--step", 0) == 0) step = true;
+        else if (a.rfind("--repeat=", 0) == 0) repeat = std::max(1, atoi(a.c_str() + 9));
         else if (a.rfind("--filter=", 0) == 0) {
             const int v = atoi(a.c_str() + 9);
             filt = (v >= 0 && v <= 4) ? (SRCNNFilterType)v : SRCNNF_Bicubic;
@@ -126,11 +129,17 @@ int main(int argc, char** argv)
     ConfigureFilterSRCNN(filt, step);
     unsigned char* out = nullptr; unsigned outsz = 0;
     unsigned char* conv = nullptr; unsigned convsz = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    const int rc = ProcessSRCNN(img.data(), w, h, d, scale, out, outsz, &conv, &convsz);
-    const auto t1 = std::chrono::steady_clock::now();
-    if (rc != 0 || !out) { printf("- Failed, error code = %d (%s)\n", rc, srcnn_last_error()); return rc; }
-    printf("- Test Ok, took %u ms.\n", (unsigned)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+    int rc = 0;
+    for (int it = 0; it < repeat; ++it) {
+        delete[] out; delete[] conv; out = nullptr; conv = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = ProcessSRCNN(img.data(), w, h, d, scale, out, outsz, &conv, &convsz);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (rc != 0 || !out) { printf("- Failed, error code = %d (%s)\n", rc, srcnn_last_error()); return rc; }
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (repeat == 1) printf("- Test Ok, took %u ms.\n", (unsigned)ms);
+        else printf("- Test Ok, took %.2f ms (call %d of %d).\n", ms, it + 1, repeat);
+    }
 
     unsigned ow = 0, oh = 0;
     if (srcnn_output_size(w, h, scale, step ? 1 : 0, &ow, &oh) != 0 || (size_t)ow * oh * d != outsz) {
