@@ -373,3 +373,15 @@ def test_processsrcnn_large_image_pipelined_path(srcnn, oracle_lib):
         assert np.array_equal(conv.reshape(want_conv.shape), want_conv), "d=%d conv" % d
         rc, out2, none = srcnn.ProcessSRCNN(img, 1100, 640, d, 2.0, want_conv=False)
         assert rc == 0 and none is None and np.array_equal(out2, out)
+
+
+def test_processsrcnn_pipelined_path_other_filter_and_ratio(srcnn, oracle_lib):
+    """The banded path with the general resampler: x1.5 with Lanczos3 (7-tap table, odd band boundaries)."""
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (900, 1400, 3), dtype=np.uint8)
+    img[200:500, 300:900] = (np.arange(600)[None, :, None] % 256).astype(np.uint8)
+    want_rgb, want_conv = oracle_lib.process(img, 1.5, 3)
+    got_rgb, got_conv = srcnn.process_u8(img, 1.5, 3)
+    assert got_rgb.shape == want_rgb.shape and got_rgb.nbytes >= (8 << 20)
+    assert np.array_equal(got_rgb, want_rgb)
+    assert np.array_equal(got_conv, want_conv)
