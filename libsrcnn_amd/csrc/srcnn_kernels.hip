@@ -946,17 +946,123 @@ void launch_conv2_planes(const float* C1, size_t n, float* C2v, hipStream_t s)
     hipLaunchKernelGGL(k_conv2_planes, grid, dim3(256), 0, s, C1, n, C2v);
 }
 
+// ---- 4-pixels-per-thread forms of the colour shell: 16-byte plane accesses, 12/16-byte packed pixel
+//      accesses.  Same per-pixel arithmetic as the scalar kernels (which remain for unaligned spans/tails). ----
+template <int D>
+__global__ __launch_bounds__(256) void k_rgb_split4(const unsigned* __restrict__ rgb32, size_t n4,
+                                                    float4* __restrict__ Yp, float4* __restrict__ Cb,
+                                                    float4* __restrict__ Cr, float4* __restrict__ A)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n4) return;
+    unsigned wds[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) wds[k] = rgb32[q * D + k];            // D dwords = 4 pixels of D bytes
+    float yv[4], cbv[4], crv[4], av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float ch[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int byte = i * D + k;
+            ch[k] = (float)((wds[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+        }
+        const float r = ch[0], g = ch[1], b = ch[2];
+        yv[i] = (0.299f * r) + (0.587f * g) + (0.114f * b);
+        cbv[i] = 128.f - (0.1687f * r) - (0.3313f * g) + (0.5f * b);
+        crv[i] = 128.f + (0.5f * r) - (0.4187f * g) - (0.0813f * b);
+        av[i] = ch[3];
+    }
+    Yp[q] = make_float4(yv[0], yv[1], yv[2], yv[3]);
+    Cb[q] = make_float4(cbv[0], cbv[1], cbv[2], cbv[3]);
+    Cr[q] = make_float4(crv[0], crv[1], crv[2], crv[3]);
+    if (D == 4) A[q] = make_float4(av[0], av[1], av[2], av[3]);
+}
+
+template <int D, bool CONV>
+__global__ __launch_bounds__(256) void k_ycc_merge4(const float4* __restrict__ Yp, const float4* __restrict__ Cb,
+                                                    const float4* __restrict__ Cr, const float4* __restrict__ A,
+                                                    size_t n4, unsigned* __restrict__ rgb32, unsigned* __restrict__ conv32)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n4) return;
+    const float4 y4 = Yp[q], cb4 = Cb[q], cr4 = Cr[q];
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (D == 4) a4 = A[q];
+    const float ys[4] = {y4.x, y4.y, y4.z, y4.w}, cbs[4] = {cb4.x, cb4.y, cb4.z, cb4.w};
+    const float crs[4] = {cr4.x, cr4.y, cr4.z, cr4.w}, as[4] = {a4.x, a4.y, a4.z, a4.w};
+    unsigned wds[D] = {};
+    unsigned cw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float fy = ys[i], cb = cbs[i] - 128.f, cr = crs[i] - 128.f;
+        unsigned char px[4];
+        px[0] = to_u8_sat(fy + 45.f * cr / 32.f);
+        px[1] = to_u8_sat(fy - (11.f * cb + 23.f * cr) / 32.f);
+        px[2] = to_u8_sat(fy + 113.f * cb / 64.f);
+        px[3] = to_u8_sat(as[i]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int byte = i * D + k;
+            wds[byte >> 2] |= (unsigned)px[k] << (8 * (byte & 3));
+        }
+        cw |= (unsigned)(unsigned char)fy << (8 * i);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) rgb32[q * D + k] = wds[k];
+    if (CONV) conv32[q] = cw;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 void launch_rgb_split(const unsigned char* rgb, size_t n, int d, float* Yp, float* Cb, float* Cr, float* A,
                       hipStream_t s)
 {
-    hipLaunchKernelGGL(k_rgb_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rgb, n, d, Yp, Cb, Cr, A);
+    size_t done = 0;
+    if ((d == 3 || d == 4) && n >= 1024 && aligned16(Yp) && aligned16(Cb) && aligned16(Cr) && (d == 3 || aligned16(A)) &&
+        (reinterpret_cast<uintptr_t>(rgb) & 3u) == 0) {
+        const size_t n4 = n / 4;
+        const dim3 grid((unsigned)((n4 + 255) / 256));
+        if (d == 3)
+            hipLaunchKernelGGL((k_rgb_split4<3>), grid, dim3(256), 0, s, reinterpret_cast<const unsigned*>(rgb), n4,
+                               reinterpret_cast<float4*>(Yp), reinterpret_cast<float4*>(Cb), reinterpret_cast<float4*>(Cr),
+                               reinterpret_cast<float4*>(A));
+        else
+            hipLaunchKernelGGL((k_rgb_split4<4>), grid, dim3(256), 0, s, reinterpret_cast<const unsigned*>(rgb), n4,
+                               reinterpret_cast<float4*>(Yp), reinterpret_cast<float4*>(Cb), reinterpret_cast<float4*>(Cr),
+                               reinterpret_cast<float4*>(A));
+        done = n4 * 4;
+    }
+    if (done < n) {
+        const size_t rem = n - done;
+        hipLaunchKernelGGL(k_rgb_split, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, s, rgb + done * d, rem, d,
+                           Yp + done, Cb + done, Cr + done, A ? A + done : A);
+    }
 }
 
 void launch_ycc_merge(const float* Yp, const float* Cb, const float* Cr, const float* A, size_t n, int d,
                       unsigned char* rgb, unsigned char* conv_opt, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ycc_merge, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yp, Cb, Cr, A, n, d, rgb,
-                       conv_opt);
+    size_t done = 0;
+    if ((d == 3 || d == 4) && n >= 1024 && aligned16(Yp) && aligned16(Cb) && aligned16(Cr) && (d == 3 || aligned16(A)) &&
+        (reinterpret_cast<uintptr_t>(rgb) & 3u) == 0 && (!conv_opt || (reinterpret_cast<uintptr_t>(conv_opt) & 3u) == 0)) {
+        const size_t n4 = n / 4;
+        const dim3 grid((unsigned)((n4 + 255) / 256));
+        const float4 *y4 = reinterpret_cast<const float4*>(Yp), *cb4 = reinterpret_cast<const float4*>(Cb);
+        const float4 *cr4 = reinterpret_cast<const float4*>(Cr), *a4 = reinterpret_cast<const float4*>(A);
+        unsigned* o32 = reinterpret_cast<unsigned*>(rgb);
+        unsigned* c32 = reinterpret_cast<unsigned*>(conv_opt);
+        if (d == 3 && conv_opt) hipLaunchKernelGGL((k_ycc_merge4<3, true>), grid, dim3(256), 0, s, y4, cb4, cr4, a4, n4, o32, c32);
+        else if (d == 3) hipLaunchKernelGGL((k_ycc_merge4<3, false>), grid, dim3(256), 0, s, y4, cb4, cr4, a4, n4, o32, c32);
+        else if (conv_opt) hipLaunchKernelGGL((k_ycc_merge4<4, true>), grid, dim3(256), 0, s, y4, cb4, cr4, a4, n4, o32, c32);
+        else hipLaunchKernelGGL((k_ycc_merge4<4, false>), grid, dim3(256), 0, s, y4, cb4, cr4, a4, n4, o32, c32);
+        done = n4 * 4;
+    }
+    if (done < n) {
+        const size_t rem = n - done;
+        hipLaunchKernelGGL(k_ycc_merge, dim3((unsigned)((rem + 255) / 256)), dim3(256), 0, s, Yp + done, Cb + done, Cr + done,
+                           A ? A + done : A, rem, d, rgb + done * d, conv_opt ? conv_opt + done : conv_opt);
+    }
 }
 
 }  // namespace srcnn
