@@ -385,3 +385,20 @@ def test_processsrcnn_pipelined_path_other_filter_and_ratio(srcnn, oracle_lib):
     assert got_rgb.shape == want_rgb.shape and got_rgb.nbytes >= (8 << 20)
     assert np.array_equal(got_rgb, want_rgb)
     assert np.array_equal(got_conv, want_conv)
+
+
+def test_soak_determinism_full_frames(srcnn):
+    """30 back-to-back runs of a resident 1920x1080 frame (and of the batch entry point) give one and the
+    same output image -- guards against hazards that only bite some waves of some launches."""
+    import hashlib
+    S = srcnn
+    h, w = 1080, 1920
+    fr = synth.frames(2, h, w, 40, "noise")
+    din = S.DeviceBuffer.from_numpy(fr)
+    dout = S.DeviceBuffer(2 * 4 * h * w * 4)
+    sums = set()
+    for _ in range(30):
+        S.check(S.lib().srcnn_y_upscale2x_f32_batch_dev(din.ptr, w, h, 2, dout.ptr, None))
+        S.sync()
+        sums.add(hashlib.sha256(dout.to_numpy(np.float32, (2, 2 * h, 2 * w)).tobytes()).hexdigest())
+    assert len(sums) == 1, sums
