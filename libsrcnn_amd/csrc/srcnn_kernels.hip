@@ -734,6 +734,108 @@ __global__ __launch_bounds__(256) void k_conv3(
 }
 
 // =============================================================================================
+// conv3 for the non-parity tiers: plain fp32 FMA chains.  At 2 VALU cycles per 64 FMAs the strict kernel's
+// one-column-per-lane window (40 ds_read_b32 per 100 FMAs) is LDS-bound, so here a lane owns 2 adjacent
+// columns x 4 rows: its 8x6 window is 24 aligned ds_read_b64 per 200 FMAs.  Tile 128 x 16, 2 channels per
+// double-buffered LDS stage.
+// =============================================================================================
+constexpr int CF_TW = 128, CF_TH = 16, CF_MC = 2;
+constexpr int CF_LW = CF_TW + 4, CF_LH = CF_TH + 4;
+constexpr int CF_CH = CF_LH * CF_LW;
+constexpr int CF_BODY = CF_MC * CF_LH / 2;          // body loads per thread per chunk (2 row slots of 128 columns)
+
+__global__ __launch_bounds__(256) void k_conv3_fast(
+    const float* __restrict__ C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows,
+    float* __restrict__ out, int out_row0, int out_rows)
+{
+    __shared__ __attribute__((aligned(16))) float tile[2][CF_MC * CF_CH];
+
+    const int tx0 = blockIdx.x * CF_TW;
+    const int ty0 = out_row0 + blockIdx.y * CF_TH;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c2_last = c2_row_base + c2_rows - 1;
+
+    const int bcol = tid & 127, bslot = tid >> 7;                       // body: 128 columns x 2 row slots
+    const int bx = min(tx0 + bcol, W - 1);
+    const int hrow = tid >> 2, hq = tid & 3;                            // halo: 4 columns per staged row
+    const int hx = clampi(tx0 + (hq < 2 ? hq - 2 : 126 + hq), 0, W - 1);
+    const int hlc = hq < 2 ? hq : 128 + hq;
+
+    float body[CF_BODY], halo = 0.f;
+    auto row_of = [&](int r) {
+        int gy = clampi(ty0 + r - 2, 0, H - 1);
+        gy = clampi(gy, c2_row_base, c2_last);
+        return gy - c2_row_base;
+    };
+    auto issue = [&](int mc) {
+#pragma unroll
+        for (int i = 0; i < CF_BODY; ++i) {
+            const int m = i / (CF_LH / 2), r = 2 * (i % (CF_LH / 2)) + bslot;      // staged row 2*i + bslot
+            body[i] = C2[(size_t)(mc + m) * plane_stride + (size_t)row_of(r) * W + bx];
+        }
+        if (hrow < CF_MC * CF_LH) {
+            const int m = hrow / CF_LH, r = hrow - m * CF_LH;
+            halo = C2[(size_t)(mc + m) * plane_stride + (size_t)row_of(r) * W + hx];
+        }
+    };
+    auto land = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < CF_BODY; ++i) dst[(2 * i + bslot) * CF_LW + 2 + bcol] = body[i];
+        if (hrow < CF_MC * CF_LH) dst[hrow * CF_LW + hlc] = halo;
+    };
+
+    float sum[4][2] = {};
+    issue(0);
+    land(tile[0]);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < C2N / CF_MC; ++c) {
+        const float* cur = tile[c & 1];
+        if (c + 1 < C2N / CF_MC) issue((c + 1) * CF_MC);
+#pragma unroll 1
+        for (int m = 0; m < CF_MC; ++m) {
+            const float* t = cur + m * CF_CH + (wv * 4) * CF_LW + 2 * lane;     // window columns 2l-2 .. 2l+3 -> index 2l..2l+5
+            const float* wm = cW.w3[c * CF_MC + m];
+            float win[8][6];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const float2 v = *reinterpret_cast<const float2*>(t + r * CF_LW + 2 * p);
+                    win[r][2 * p] = v.x; win[r][2 * p + 1] = v.y;
+                }
+            float a[4][2] = {};
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) {
+                    const float wgt = wm[dy * 5 + dx];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[q][0] = __builtin_fmaf(wgt, win[q + dy][dx], a[q][0]);
+                        a[q][1] = __builtin_fmaf(wgt, win[q + dy][dx + 1], a[q][1]);
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sum[q][0] += a[q][0]; sum[q][1] += a[q][1]; }
+        }
+        if (c + 1 < C2N / CF_MC) land(tile[(c + 1) & 1]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = ty0 + wv * 4 + q;
+        if (row < H && row < out_row0 + out_rows) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int x = tx0 + 2 * lane + e;
+                if (x < W) out[(size_t)(row - out_row0) * W + x] = fminf(fmaxf(sum[q][e] + cW.b3, 0.f), 255.f);
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // Unfused layer 1 and layer 2 (stage-level entry points; not used by the hot path).
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_conv1_planes(const float* __restrict__ Y, int W, int H,
@@ -925,6 +1027,12 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
                   int out_row0, int out_rows, bool strict, hipStream_t s)
 {
     if (out_rows <= 0) return;
+    if (!strict) {
+        dim3 gridf(cdiv(W, CF_TW), cdiv(out_rows, CF_TH));
+        hipLaunchKernelGGL(k_conv3_fast, gridf, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows, out,
+                           out_row0, out_rows);
+        return;
+    }
     dim3 grid(cdiv(W, 64), cdiv(out_rows, 16));
     if (strict)
         hipLaunchKernelGGL((k_conv3<true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
