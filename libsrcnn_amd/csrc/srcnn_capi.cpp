@@ -31,6 +31,15 @@ using namespace srcnn;
 
 thread_local char g_err[512] = "";
 
+}  // namespace
+
+namespace srcnn {
+// shared with srcnn_comm.cpp so that srcnn_last_error() also reports RCCL failures
+void set_last_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+}  // namespace srcnn
+
+namespace {
+
 int fail(int code, const char* fmt, ...)
 {
     va_list ap;

@@ -14,6 +14,8 @@
 
 #include "../../include/srcnn_amd.h"
 
+namespace srcnn { void set_last_error(const char* msg); }
+
 namespace {
 
 static_assert(sizeof(ncclUniqueId) == SRCNN_COMM_ID_BYTES, "unique id size");
@@ -44,7 +46,11 @@ int load()
     if (R.h) return 0;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
-    if (!R.h) { snprintf(g_cerr, sizeof g_cerr, "dlopen(librccl) failed: %s", dlerror()); return SRCNN_E_COMM; }
+    if (!R.h) {
+        snprintf(g_cerr, sizeof g_cerr, "dlopen(librccl) failed: %s", dlerror());
+        srcnn::set_last_error(g_cerr);
+        return SRCNN_E_COMM;
+    }
 #define SYM(f) R.f = reinterpret_cast<decltype(R.f)>(dlsym(R.h, "nccl" #f)); if (!R.f) { snprintf(g_cerr, sizeof g_cerr, "missing nccl" #f); return SRCNN_E_COMM; }
     SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(GroupStart) SYM(GroupEnd)
     SYM(Send) SYM(Recv) SYM(AllGather) SYM(AllReduce) SYM(GetErrorString)
@@ -57,7 +63,7 @@ int load()
         ncclResult_t r_ = (expr);                                                              \
         if (r_ != ncclSuccess) {                                                               \
             snprintf(g_cerr, sizeof g_cerr, "%s -> %s", #expr, R.GetErrorString(r_));          \
-            fprintf(stderr, "libsrcnn_amd: %s\n", g_cerr);                                     \
+            srcnn::set_last_error(g_cerr);                                                     \
             return SRCNN_E_COMM;                                                               \
         }                                                                                      \
     } while (0)
