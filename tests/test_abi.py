@@ -85,3 +85,36 @@ def test_output_size_matches_reference_geometry(S, golden):
     assert S.output_size(24, 20, 3.0, True) == p["rgb_x3step_out"].shape[1::-1]
     with pytest.raises(S.SrcnnError):
         S.output_size(0, 4, 2.0)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference header not present on this machine")
+def test_program_built_against_reference_header_links_and_runs(S, tmp_path):
+    """A C++ program compiled against the REFERENCE's own libsrcnn.h (default argument, reference parameters,
+    enum) links against libsrcnn_amd.so unchanged and gets the reference's early return codes."""
+    import subprocess
+    src = tmp_path / "app.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "libsrcnn.h"
+int main() {
+    ConfigureFilterSRCNN(SRCNNF_Lanczos3);            // default stepscale argument from the reference header
+    ConfigureFilterSRCNN(SRCNNF_Bicubic, false);
+    unsigned char px[4 * 4 * 3] = {0};
+    unsigned char* out = nullptr; unsigned outsz = 0;
+    int a = ProcessSRCNN(nullptr, 4, 4, 3, 2.0f, out, outsz, nullptr, nullptr);
+    int b = ProcessSRCNN(px, 4, 4, 3, -1.0f, out, outsz, nullptr, nullptr);
+    int c = ProcessSRCNN(px, 4, 4, 3, 2.0f, out, outsz, nullptr, nullptr);   // 0 on a GPU box, -200 without a device
+    std::printf("%d %d %d %u\n", a, b, c, outsz);
+    delete[] out;
+    return 0;
+}
+''')
+    exe = tmp_path / "app"
+    libdir = os.path.dirname(S.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", str(src), "-I/root/reference/src", "-L" + libdir, "-lsrcnn_amd",
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120).stdout.split()
+    assert out[0] == "-1" and out[1] == "-2"
+    assert out[2] in ("0", "-200")
+    if out[2] == "0":
+        assert out[3] == str(8 * 8 * 3)
