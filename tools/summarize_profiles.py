@@ -18,7 +18,7 @@ os.makedirs(dst, exist_ok=True)
 
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None      # the latest collection wins
 
 
 def short(name):
