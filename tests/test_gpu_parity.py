@@ -402,3 +402,17 @@ def test_soak_determinism_full_frames(srcnn):
         S.sync()
         sums.add(hashlib.sha256(dout.to_numpy(np.float32, (2, 2 * h, 2 * w)).tobytes()).hexdigest())
     assert len(sums) == 1, sums
+
+
+def test_size_limits_are_reported_not_crashed(srcnn):
+    """Output heights beyond the 65 535-row limit (rows are a grid dimension) and 32-bit ProcessSRCNN byte counts
+    are refused with an error code before anything is launched or allocated."""
+    S = srcnn
+    dummy = S.DeviceBuffer(64)
+    rc = S.lib().srcnn_y_upscale2x_f32_dev(dummy.ptr, 8, 40000, dummy.ptr, None)
+    assert rc == -203, rc
+    assert b"too large" in S.lib().srcnn_last_error()
+    # 40000 x 40000 x 3 at x2 would need a 19 GB output: outbuffsz is 32-bit in the reference API
+    img = np.zeros((4, 4, 3), np.uint8)
+    rc, out, conv = S.ProcessSRCNN(img, 40000, 40000, 3, 2.0)
+    assert rc in (-11, -203) and out is None
