@@ -86,3 +86,25 @@ def test_bicubic_2x_phase_structure(oracle_lib):
         ref = odd if u % 2 else odd[::-1]
         assert np.allclose(nz, ref, rtol=0, atol=1e-15), (u, nz)
     assert np.isclose(w[0, 0], 1.0308924485125861) and np.isclose(w[0, 1], -0.030892448512586119)
+
+
+def test_translation_property_of_the_path(oracle_lib):
+    """Size-independent property: away from the borders the path is translation-equivariant -- shifting the
+    input by (dy, dx) shifts the 2x output by (2dy, 2dx), bit for bit (every stage is position-invariant;
+    only the truncate-and-renormalise resampler borders and the clamp-to-edge padding break it)."""
+    rng = np.random.default_rng(99)
+    big = (rng.random((60, 72)) * 255).astype(np.float32)
+    a = oracle_lib.y_path(big[:48, :56])
+    b = oracle_lib.y_path(big[3:51, 5:61])             # same content shifted by (3, 5)
+    m = 16                                            # > 6-px receptive field + resampler border zone
+    assert np.array_equal(a[2 * 3 + m: 96 - m, 2 * 5 + m: 112 - m].view(np.uint32),
+                          b[m: 96 - 2 * 3 - m, m: 112 - 2 * 5 - m].view(np.uint32))
+
+
+def test_output_range_and_saturation(oracle_lib):
+    """convolution55 clamps to [0,255] (src/libsrcnn.cpp:521-522): holds for wild inputs too."""
+    rng = np.random.default_rng(3)
+    y = ((rng.random((20, 28)) - 0.3) * 900).astype(np.float32)
+    out = oracle_lib.y_path(y)
+    assert out.min() >= 0.0 and out.max() <= 255.0
+    assert (out == 0).any() and (out == 255).any()
