@@ -416,3 +416,14 @@ def test_size_limits_are_reported_not_crashed(srcnn):
     img = np.zeros((4, 4, 3), np.uint8)
     rc, out, conv = S.ProcessSRCNN(img, 40000, 40000, 3, 2.0)
     assert rc in (-11, -203) and out is None
+
+
+def test_full_size_translation_property(srcnn):
+    """BASELINE frame size (3840x2160 -> 7680x4320), size-independent property with no oracle involved:
+    shifting the input by (2, 4) pixels shifts the interior of the output by (4, 8), bit for bit."""
+    big = synth.plane(2164, 3848, synth.SEED0 + 2024, "noise")
+    a = srcnn.y_upscale2x(np.ascontiguousarray(big[:2160, :3840]))
+    b = srcnn.y_upscale2x(np.ascontiguousarray(big[2:2162, 4:3844]))
+    m = 16
+    assert np.array_equal(a[4 + m: 4320 - m, 8 + m: 7680 - m].view(np.uint32),
+                          b[m: 4320 - 4 - m, m: 7680 - 8 - m].view(np.uint32))
