@@ -323,7 +323,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
                         a2 = W1s[(t + 2) * 64 + lane];
                         b2 = yrow[((t + 2) / 9) * M_LW + ((t + 2) % 9)];
                     }
-                    acc += d;
+                    // tap 0: the reference's "0 + p" is p itself (a -0 product differs from the reference's +0 only
+                    // until the first non-(-0) term or the bias add, never in the stored value), so the first
+                    // result simply becomes the accumulator
+                    if (t == 0) acc = d; else acc += d;
                     PIN(acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -379,6 +382,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
                         PIN(d);
                         a1 = a2; b1 = b2;
                         if (fp + 2 < 16) { a2 = w2p[(fp + 2) * 64 + lane]; b2 = myC1[(fp + 2) * 64 + lane]; }
+                        if (blk == 0 && fp == 0) acc2 = __builtin_shufflevector(d, d, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                        else
                         acc2 += __builtin_shufflevector(d, d, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
                         acc2 += __builtin_shufflevector(d, d, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
                         PIN(acc2);
