@@ -706,7 +706,9 @@ __global__ __launch_bounds__(256) void k_conv3(
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float pr = wv_ * win[q + dy][dx];
-                            a[q] = a[q] + (double)pr;
+                            // tap 0: "0.0 + p" is p (a -0 differs from the reference's +0 only until it is folded
+                            // into the fp32 running sum, which can never be -0)
+                            a[q] = (dy == 0 && dx == 0) ? (double)pr : a[q] + (double)pr;
                         }
                     }
 #pragma unroll
