@@ -272,6 +272,7 @@ def main():
             "roofline": {"kernel": "k_conv12_mfma (conv 9x9x1->64 + ReLU + conv 1x1x64->32 + ReLU)",
                          "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                         "frac_of_no_fma_ceiling": round(achieved / (PEAK_F32_TFLOPS / 2), 4),
                          "avg_launch_ms": round(avg12, 4), "launches": int(c12_n),
                          "flops_per_launch": flops12,
                          "note": "strict mode rounds product and sum separately (no FMA): ceiling is 0.5 of this peak",
