@@ -52,13 +52,16 @@ __global__ void probe(const float* w, const float* y, float* d_mfma, float* d_mu
     }
 }
 
-template <int V>   // 0: bf16 mfma only, 1: + 8 pk_add (the 32x32 tile = 16 regs), 2: 8 pk_add only
+template <int V>   // 0: bf16 mfma only, 1: + 8 pk_add (the 32x32 tile = 16 regs), 2: 8 pk_add only,
+                   // 3: 32 independent v_add_f32 only, 4: bf16 mfma + those 32 adds (throughput-bound co-issue test)
 __global__ __launch_bounds__(256, 2) void tim(float* out, unsigned long long* clk, int iters)
 {
     const int lane = threadIdx.x & 63;
     bf16x8 a, b;
     for (int e = 0; e < 8; ++e) { a[e] = (short)(0x3f80 + lane + e); b[e] = (short)(0x3f00 + lane * 3 + e); }
     f32x16 z = {}, acc = {}, d_cur = {};
+    float wide[32]; float inc = 1e-7f * lane;
+    for (int i = 0; i < 32; ++i) wide[i] = i;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if constexpr (V == 0) {
@@ -74,13 +77,23 @@ __global__ __launch_bounds__(256, 2) void tim(float* out, unsigned long long* cl
             __builtin_amdgcn_sched_barrier(0);
             acc += d; PIN(acc);
             __builtin_amdgcn_sched_barrier(0);
-        } else {
+        } else if constexpr (V == 2) {
             acc += d_cur; PIN(acc);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if constexpr (V == 4) {
+                f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0); PIN(d);
+                __builtin_amdgcn_sched_barrier(0);
+                d_cur = d;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(wide[i]) : "v"(inc));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0; for (int i = 0; i < 16; ++i) s += acc[i] + d_cur[i];
+    for (int i = 0; i < 32; ++i) s += wide[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
@@ -131,6 +144,8 @@ int main()
         hipLaunchKernelGGL(tim<0>, dim3(grid), dim3(256), 0, 0, d_out, d_clk, iters); report("bf16 mfma only", 1, 0);
         hipLaunchKernelGGL(tim<1>, dim3(grid), dim3(256), 0, 0, d_out, d_clk, iters); report("bf16 mfma + 8 pk_add", 2, 1);
         hipLaunchKernelGGL(tim<2>, dim3(grid), dim3(256), 0, 0, d_out, d_clk, iters); report("8 pk_add only", 1, 1);
+        hipLaunchKernelGGL(tim<3>, dim3(grid), dim3(256), 0, 0, d_out, d_clk, iters); report("32 v_add_f32 only", 1, 1);
+        hipLaunchKernelGGL(tim<4>, dim3(grid), dim3(256), 0, 0, d_out, d_clk, iters); report("bf16 mfma + 32 v_add_f32", 1, 1);
     }
     return 0;
 }
