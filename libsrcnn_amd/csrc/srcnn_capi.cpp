@@ -344,7 +344,8 @@ int y_path_rows(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned
                 unsigned r0, unsigned r1, float* d_out, hipStream_t s)
 {
     if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
-    if (dh > 65535u || h > 65535u || dw > 0x7fffffu) return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large (rows are a grid dimension)", dw, dh);
+    if (dh > (1u << 20) || h > (1u << 20) || dw > 0x7fffffu || (r1 - r0) > 65535u * 16u)
+        return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large", dw, dh);
     Workspace& ws = workspace_for(s);
     // rows of layer-2 activations that conv3 touches (clamp-to-edge of the ACTIVATIONS at the true
     // border), and rows of upscaled Y that conv1 touches for those.
@@ -555,7 +556,23 @@ int srcnn_y_path_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw,
     if ((rc = check_plane(d_in, w, h, d_out))) return rc;
     if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
     if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
-    return y_path_rows(d_in, w, h, dw, dh, filter, 0, dh, d_out, (hipStream_t)stream);
+    // The 32 layer-2 planes are the big scratch (128 B per output pixel).  Frames whose planes would exceed the
+    // workspace budget (default 16 GiB, SRCNN_MAX_WORKSPACE_MB) are produced in horizontal bands -- bit-identical
+    // to the whole frame -- so a 16K x 16K output needs the same scratch as an 8K one.
+    static const size_t budget = [] {
+        const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
+        const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
+        return std::max<size_t>(mb, 1) << 20;
+    }();
+    const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
+    if (row_bytes * dh <= budget) return y_path_rows(d_in, w, h, dw, dh, filter, 0, dh, d_out, (hipStream_t)stream);
+    const size_t fit = budget / row_bytes;
+    const unsigned band = (unsigned)std::max<size_t>(16, fit > 4 ? fit - 4 : 1);
+    for (unsigned r0 = 0; r0 < dh; r0 += band) {
+        const unsigned r1 = std::min(dh, r0 + band);
+        if ((rc = y_path_rows(d_in, w, h, dw, dh, filter, r0, r1, d_out + (size_t)r0 * dw, (hipStream_t)stream))) return rc;
+    }
+    return SRCNN_OK;
 }
 
 int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_out, void* stream)
@@ -620,7 +637,7 @@ int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned d
     if ((rc = check_plane(d_in, w, h, d_out))) return rc;
     if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
     if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
-    if (dh > 65535u || h > 65535u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
+    if (dh > (1u << 20) || h > (1u << 20)) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
     Workspace& ws = workspace_for((hipStream_t)stream);
     rc = resample_rows_range(d_in, w, h, dw, dh, filter, 0, dh, d_out, ws, (hipStream_t)stream);
     if (rc) return rc;

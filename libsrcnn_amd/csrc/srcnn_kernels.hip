@@ -58,16 +58,18 @@ __global__ __launch_bounds__(256) void k_resample_cols(   // vertical pass: [src
     const int* __restrict__ first, const int* __restrict__ taps, const double* __restrict__ wt, int stride)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = dst_row0 + blockIdx.y;
-    if (x >= w || blockIdx.y >= (unsigned)dst_rows) return;
-    const int s0 = first[y], n = taps[y];
-    const double* wr = wt + (size_t)y * stride;
-    double acc = 0.0;
-    for (int t = 0; t < n; ++t) {
-        const double px = (double)src[(size_t)(s0 + t - src_row_base) * w + x];
-        acc = acc + wr[t] * px;
+    if (x >= w) return;
+    for (int ry = blockIdx.y; ry < dst_rows; ry += gridDim.y) {     // gridDim.y is capped at 65535
+        const int y = dst_row0 + ry;
+        const int s0 = first[y], n = taps[y];
+        const double* wr = wt + (size_t)y * stride;
+        double acc = 0.0;
+        for (int t = 0; t < n; ++t) {
+            const double px = (double)src[(size_t)(s0 + t - src_row_base) * w + x];
+            acc = acc + wr[t] * px;
+        }
+        dst[(size_t)ry * w + x] = (float)acc;
     }
-    dst[(size_t)blockIdx.y * w + x] = (float)acc;
 }
 
 __global__ __launch_bounds__(256) void k_resample_rows(   // horizontal pass: [rows x src_w] -> [rows x dst_w]
@@ -75,14 +77,15 @@ __global__ __launch_bounds__(256) void k_resample_rows(   // horizontal pass: [r
     const int* __restrict__ first, const int* __restrict__ taps, const double* __restrict__ wt, int stride)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= dst_w || y >= rows) return;
+    if (x >= dst_w) return;
     const int s0 = first[x], n = taps[x];
     const double* wr = wt + (size_t)x * stride;
-    const float* in = src + (size_t)y * src_w + s0;
-    double acc = 0.0;
-    for (int t = 0; t < n; ++t) acc = acc + wr[t] * (double)in[t];
-    dst[(size_t)y * dst_w + x] = (float)acc;
+    for (int y = blockIdx.y; y < rows; y += gridDim.y) {
+        const float* in = src + (size_t)y * src_w + s0;
+        double acc = 0.0;
+        for (int t = 0; t < n; ++t) acc = acc + wr[t] * (double)in[t];
+        dst[(size_t)y * dst_w + x] = (float)acc;
+    }
 }
 
 // Same pass for tables with at most RS_MAXT taps (every up-scale with the five filters): a thread keeps the
@@ -94,15 +97,14 @@ __global__ __launch_bounds__(256) void k_resample_rows_reg(
     const int* __restrict__ first, const int* __restrict__ taps, const double* __restrict__ wt, int stride)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y0 = blockIdx.y * RS_RPT;
     if (x >= dst_w) return;
     const int s0 = first[x], n = taps[x];
     const double* wr = wt + (size_t)x * stride;
     double w[RS_MAXT];
 #pragma unroll
     for (int t = 0; t < RS_MAXT; ++t) w[t] = t < n ? wr[t] : 0.0;
-    const int y1 = min(y0 + RS_RPT, rows);
-    for (int y = y0; y < y1; ++y) {
+    for (int yb = blockIdx.y * RS_RPT; yb < rows; yb += gridDim.y * RS_RPT)
+    for (int y = yb; y < min(yb + RS_RPT, rows); ++y) {
         const float* in = src + (size_t)y * src_w + s0;
         double acc = 0.0;
 #pragma unroll
@@ -929,7 +931,7 @@ void launch_resample_cols(const float* src, int w, int src_row_base, float* dst,
                           const DevAxisTable& t, hipStream_t s)
 {
     if (dst_rows <= 0) return;
-    dim3 grid(cdiv(w, 256), dst_rows);
+    dim3 grid(cdiv(w, 256), std::min(dst_rows, 65535));
     hipLaunchKernelGGL(k_resample_cols, grid, dim3(256), 0, s, src, w, src_row_base, dst, dst_row0, dst_rows,
                        t.first, t.taps, t.weight, t.stride);
 }
@@ -939,12 +941,12 @@ void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, in
 {
     if (rows <= 0) return;
     if (t.max_taps <= RS_MAXT) {
-        dim3 grid(cdiv(dst_w, 256), cdiv(rows, RS_RPT));
+        dim3 grid(cdiv(dst_w, 256), std::min<unsigned>(cdiv(rows, RS_RPT), 65535u));
         hipLaunchKernelGGL(k_resample_rows_reg, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
                            t.weight, t.stride);
         return;
     }
-    dim3 grid(cdiv(dst_w, 256), rows);
+    dim3 grid(cdiv(dst_w, 256), std::min(rows, 65535));
     hipLaunchKernelGGL(k_resample_rows, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
                        t.weight, t.stride);
 }

@@ -405,11 +405,11 @@ def test_soak_determinism_full_frames(srcnn):
 
 
 def test_size_limits_are_reported_not_crashed(srcnn):
-    """Output heights beyond the 65 535-row limit (rows are a grid dimension) and 32-bit ProcessSRCNN byte counts
-    are refused with an error code before anything is launched or allocated."""
+    """Output heights beyond the 2^20-row limit and 32-bit ProcessSRCNN byte counts are refused with an error code
+    before anything is launched or allocated."""
     S = srcnn
     dummy = S.DeviceBuffer(64)
-    rc = S.lib().srcnn_y_upscale2x_f32_dev(dummy.ptr, 8, 40000, dummy.ptr, None)
+    rc = S.lib().srcnn_y_upscale2x_f32_dev(dummy.ptr, 8, 600000, dummy.ptr, None)     # 1.2 M output rows
     assert rc == -203, rc
     assert b"too large" in S.lib().srcnn_last_error()
     # 40000 x 40000 x 3 at x2 would need a 19 GB output: outbuffsz is 32-bit in the reference API
@@ -427,3 +427,23 @@ def test_full_size_translation_property(srcnn):
     m = 16
     assert np.array_equal(a[4 + m: 4320 - m, 8 + m: 7680 - m].view(np.uint32),
                           b[m: 4320 - 4 - m, m: 7680 - 8 - m].view(np.uint32))
+
+
+def test_tall_frame_and_workspace_budget_banding(oracle_lib, tmp_path):
+    """(1) A frame taller than 65 535 output rows (the old grid-dimension limit); (2) with the workspace budget
+    forced down to 1 MB the same call is produced in many horizontal bands.  Both bit-identical to the oracle.
+    The budget is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, libsrcnn_amd as S, oracle;"
+            "from libsrcnn_amd import synth; S.init(0); o = oracle.Oracle();"
+            "y = synth.plane(33000, 5, 7, 'noise');"
+            "a = np.array_equal(S.y_upscale2x(y).view(np.uint32), o.y_path(y).view(np.uint32));"
+            "z = synth.plane(150, 90, 8, 'smooth');"
+            "b = np.array_equal(S.y_upscale2x(z).view(np.uint32), o.y_path(z).view(np.uint32));"
+            "print('TALL', a, 'BANDED', b)") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_MAX_WORKSPACE_MB="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert "TALL True BANDED True" in r.stdout, r.stdout + r.stderr
