@@ -100,7 +100,9 @@ int   srcnn_event_elapsed_ms(void* start, void* stop, float* ms);   /* syncs on 
  * d_in : planar float32 Y, w*h, row-major, values nominally 0..255 (device memory)
  * d_out: planar float32 Y', (2w)*(2h) (device memory)
  * Launches asynchronously on `stream` (NULL = default stream); scratch comes from a grow-only
- * per-stream workspace owned by the library, so steady-state calls do no allocation. */
+ * per-stream workspace owned by the library, so steady-state calls do no allocation.  The scratch is
+ * 128 B per output pixel; above a budget (env SRCNN_MAX_WORKSPACE_MB, default 16384) the frame is
+ * produced in horizontal bands internally, with identical results.  Limits: 2^20 output rows, 2^31 pixels. */
 int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_out, void* stream);
 
 /* Same for `nframes` frames stored back to back (config "batch of 64 1080p frames" /
