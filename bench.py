@@ -127,6 +127,21 @@ def side_workload(args):
             S.check(L.srcnn_y_upscale2x_f32_stream(frames.ctypes.data, w, h, F, out.ctypes.data, 1))
         mpix_step = world * F * 4 * w * h / 1e6
         label = "%d host-resident 3840x2160 frames per rank per step, H2D + compute + D2H overlapped, hipGraph per slot" % F
+    elif args.workload == "frames-graph":
+        import ctypes as C
+        w, h, F = 3840, 2160, args.frames
+        d_in = S.DeviceBuffer(F * w * h * 4)
+        d_out = S.DeviceBuffer(F * 4 * w * h * 4)
+        for f in range(F):
+            d_in.upload(synth.plane(h, w, synth.SEED0 + rank * F + f, "smooth"), offset=f * w * h * 4)
+        st = S.Stream()
+        gh = C.c_void_p()
+        S.check(L.srcnn_batch_graph_create(d_in.ptr, w, h, F, d_out.ptr, st.handle, C.byref(gh)))
+
+        def step():
+            S.check(L.srcnn_batch_graph_launch(gh))
+        mpix_step = world * F * 4 * w * h / 1e6
+        label = "%d resident 3840x2160 frames per rank per step, replayed from one captured hipGraph" % F
     else:
         w, h, F = 1920, 1080, 64
         d_in = S.DeviceBuffer(F * w * h * 4)
@@ -172,11 +187,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4, help="4K frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="frames", choices=["frames", "tiled8k", "host-stream", "batch1080p"],
+    ap.add_argument("--workload", default="frames", choices=["frames", "frames-graph", "tiled8k", "host-stream", "batch1080p"],
                     help="frames (default, the headline metric): resident 4K frames sharded across ranks; "
                          "tiled8k: ONE 7680x4320 frame -> 15360x8640, output bands across ranks + RCCL gather; "
                          "host-stream: PCIe-inclusive stream of 4K frames from host memory (hipGraph per slot); "
-                         "batch1080p: 64 resident 1920x1080 frames per step")
+                         "batch1080p: 64 resident 1920x1080 frames per step; "
+                         "frames-graph: the headline workload replayed from one captured hipGraph per step")
     args = ap.parse_args()
     if args.workload != "frames":
         return side_workload(args)

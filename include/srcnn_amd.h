@@ -110,6 +110,16 @@ int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* 
 int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, unsigned nframes,
                                     float* d_out, void* stream);
 
+/* The batch call captured once into a hipGraph and replayed (config "stream of frames ... with per-GPU hipGraph
+ * capture"): create() runs the batch eagerly once (tables, workspaces), captures the same launches for these
+ * exact buffers on `stream`, and returns a handle; launch() replays it on that stream.  Results are those of
+ * srcnn_y_upscale2x_f32_batch_dev.  (On MI355X the kernels are milliseconds long, so replay and eager launches
+ * measure the same; the entry point exists for callers whose frames are small.) */
+int srcnn_batch_graph_create(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out, void* stream,
+                             void** graph);
+int srcnn_batch_graph_launch(void* graph);
+int srcnn_batch_graph_destroy(void* graph);
+
 /* One horizontal band of the output (rows [row0,row0+rows) of the 2h output rows), computed from
  * the whole input frame resident on this device: the multi-GPU tiling of ONE large frame
  * (no counterpart in the reference; halo rows come from the source frame).

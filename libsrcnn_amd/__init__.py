@@ -29,6 +29,7 @@ C_ABI_SYMBOLS = [
     "srcnn_event_elapsed_ms",
     "srcnn_profile_enable", "srcnn_profile_reset", "srcnn_profile_read",
     "srcnn_y_upscale2x_f32_dev", "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev",
+    "srcnn_batch_graph_create", "srcnn_batch_graph_launch", "srcnn_batch_graph_destroy",
     "srcnn_y_path_f32_dev", "srcnn_resample_f32_dev", "srcnn_conv1_f32_dev", "srcnn_conv2_f32_dev",
     "srcnn_conv3_f32_dev", "srcnn_conv12_f32_dev",
     "srcnn_y_upscale2x_f32", "srcnn_y_upscale2x_f32_batch", "srcnn_y_upscale2x_f32_stream", "srcnn_y_path_f32",
@@ -75,6 +76,8 @@ def lib():
             "srcnn_y_upscale2x_f32_dev": (i, [vp, u, u, vp, vp]),
             "srcnn_y_upscale2x_f32_batch_dev": (i, [vp, u, u, u, vp, vp]),
             "srcnn_y_upscale2x_f32_band_dev": (i, [vp, u, u, u, u, vp, vp]),
+            "srcnn_batch_graph_create": (i, [vp, u, u, u, vp, vp, C.POINTER(vp)]),
+            "srcnn_batch_graph_launch": (i, [vp]), "srcnn_batch_graph_destroy": (i, [vp]),
             "srcnn_y_path_f32_dev": (i, [vp, u, u, u, u, i, vp, vp]),
             "srcnn_resample_f32_dev": (i, [vp, u, u, u, u, i, vp, vp]),
             "srcnn_conv1_f32_dev": (i, [vp, u, u, vp, vp]), "srcnn_conv2_f32_dev": (i, [vp, u, u, vp, vp]),

@@ -592,6 +592,53 @@ int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, u
     return SRCNN_OK;
 }
 
+namespace { struct BatchGraph { hipGraphExec_t exec; hipStream_t stream; }; }
+
+int srcnn_batch_graph_create(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out, void* stream,
+                             void** graph)
+{
+    if (!graph) return fail(SRCNN_E_ARG, "graph == NULL");
+    if (!stream) return fail(SRCNN_E_ARG, "graph capture needs a non-default stream");
+    hipStream_t s = (hipStream_t)stream;
+    // eager run first: builds tables and grows the workspace, so nothing allocates inside the capture
+    int rc = srcnn_y_upscale2x_f32_batch_dev(d_in, w, h, nframes, d_out, stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    const bool was_profiling = g.profiling;
+    g.profiling = false;                                   // event pairs cannot be timed inside a capture
+    hipGraph_t gr = nullptr;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) rc = srcnn_y_upscale2x_f32_batch_dev(d_in, w, h, nframes, d_out, stream);
+    hipError_t e2 = hipStreamEndCapture(s, &gr);
+    g.profiling = was_profiling;
+    if (e != hipSuccess || e2 != hipSuccess) return fail(SRCNN_E_HIP, "stream capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(gr);
+    if (e != hipSuccess) return fail(SRCNN_E_HIP, "hipGraphInstantiate -> %s", hipGetErrorString(e));
+    *graph = new BatchGraph{exec, s};
+    return SRCNN_OK;
+}
+
+int srcnn_batch_graph_launch(void* graph)
+{
+    if (!graph) return fail(SRCNN_E_ARG, "graph == NULL");
+    BatchGraph* b = static_cast<BatchGraph*>(graph);
+    HIP_TRY(hipGraphLaunch(b->exec, b->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_batch_graph_destroy(void* graph)
+{
+    if (!graph) return SRCNN_OK;
+    BatchGraph* b = static_cast<BatchGraph*>(graph);
+    (void)hipStreamSynchronize(b->stream);
+    (void)hipGraphExecDestroy(b->exec);
+    delete b;
+    return SRCNN_OK;
+}
+
 int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h, unsigned row0, unsigned rows,
                                    float* d_out_band, void* stream)
 {

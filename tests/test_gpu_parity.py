@@ -447,3 +447,24 @@ def test_tall_frame_and_workspace_budget_banding(oracle_lib, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_MAX_WORKSPACE_MB="1"), capture_output=True,
                        text=True, timeout=600)
     assert "TALL True BANDED True" in r.stdout, r.stdout + r.stderr
+
+
+def test_batch_graph_replay_equals_eager(srcnn):
+    """The resident batch captured into a hipGraph and replayed gives the eager batch's bytes."""
+    import ctypes as C
+    S = srcnn
+    fr = synth.frames(3, 48, 80, 300, "noise")
+    want = np.stack([S.y_upscale2x(f) for f in fr])
+    din = S.DeviceBuffer.from_numpy(fr)
+    dout = S.DeviceBuffer(want.nbytes)
+    st = S.Stream()
+    h = C.c_void_p()
+    S.check(S.lib().srcnn_batch_graph_create(din.ptr, 80, 48, 3, dout.ptr, st.handle, C.byref(h)))
+    S.check(S.lib().srcnn_memset_dev(dout.ptr, 0, want.nbytes, st.handle))
+    for _ in range(3):
+        S.check(S.lib().srcnn_batch_graph_launch(h))
+    st.sync()
+    got = dout.to_numpy(np.float32, want.shape)
+    S.check(S.lib().srcnn_batch_graph_destroy(h))
+    st.destroy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
