@@ -11,6 +11,7 @@
 //     taps[u]            number of taps actually summed (after trailing-zero trimming)
 //     weight[u*stride+t] weight of source index first[u]+t,  t < taps[u]
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
