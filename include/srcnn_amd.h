@@ -35,7 +35,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define SRCNN_AMD_ABI_VERSION 1
+#define SRCNN_AMD_ABI_VERSION 2   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts */
 
 /* error codes.  -1/-2/-11/-12/-100 are the reference's own (src/libsrcnn.cpp:951-966,883,910,636) */
 #define SRCNN_OK            0
@@ -64,7 +64,17 @@ extern "C" {
 
 /* ---- lifecycle (the reference has none: it is stateless CPU code; src/libsrcnn.cpp:91-92 are its
  *      only globals).  srcnn_init is idempotent and thread-safe; every compute call self-inits on
- *      device 0 if it was never called. ---- */
+ *      device 0 if it was never called.
+ *
+ * Threading contract.  Every entry point may be called from any host thread at any time.
+ *   - srcnn_process_u8 / ProcessSRCNN are re-entrant like the reference's (src/libsrcnn.cpp:628-923 allocates
+ *     everything per call): a call leases a private lane (streams, scratch, staging) for its duration; up to 4
+ *     run concurrently, further callers wait for a lane.
+ *   - *_dev calls take their scratch from the given stream's workspace; two threads using the SAME stream are
+ *     serialised while they enqueue, different streams are independent.
+ *   - The numerics mode is sampled once when a call starts; srcnn_set_mode never affects a call in flight.
+ *   - srcnn_stream_destroy / srcnn_batch_graph_destroy / srcnn_shutdown must not race with calls that still use
+ *     that stream / graph / the library (as with any handle). ---- */
 int         srcnn_abi_version(void);
 int         srcnn_device_count(void);              /* number of visible HIP devices (0 if none) */
 int         srcnn_init(int device);                /* bind this process to `device`, upload weights */
@@ -115,6 +125,9 @@ int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, u
  * exact buffers on `stream`, and returns a handle; launch() replays it on that stream.  Results are those of
  * srcnn_y_upscale2x_f32_batch_dev.  (On MI355X the kernels are milliseconds long, so replay and eager launches
  * measure the same; the entry point exists for callers whose frames are small.) */
+/* Lifetime: the handle owns a private scratch workspace and references to the contribution tables its kernel nodes
+ * use, so it stays valid whatever else runs on `stream` afterwards (larger frames, other graphs); it only needs
+ * `stream`, d_in and d_out to outlive it.  Destroy it before srcnn_stream_destroy(stream) / srcnn_shutdown. */
 int srcnn_batch_graph_create(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out, void* stream,
                              void** graph);
 int srcnn_batch_graph_launch(void* graph);
@@ -190,6 +203,10 @@ void srcnn_delete_array(unsigned char* p);
  * (weights row stride = window+1 doubles). */
 int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, int* right, double* weights);
 
+/* Test hook: number of contribution tables currently cached (bounded, only unreferenced tables are evicted) and
+ * of ProcessSRCNN lanes created so far (at most 4). */
+int srcnn_debug_counts(int* tables, int* lanes);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI only for the final band gather ----
  * The unique id is produced on rank 0 and handed to the other ranks by the caller's own
  * bootstrap (torch.distributed/gloo store, MPI, a file ...). */
@@ -197,9 +214,14 @@ int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, 
 int srcnn_comm_unique_id(unsigned char id[SRCNN_COMM_ID_BYTES]);
 int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int nranks);
 int srcnn_comm_destroy(void);
+int srcnn_comm_rank(int* rank, int* nranks);
 /* every rank contributes `count` floats at d_send; rank `root` receives nranks*count floats in
  * rank order at d_recv (ignored elsewhere).  Direct peer->root sends, one xGMI link each. */
 int srcnn_comm_gather_f32(const float* d_send, size_t count, float* d_recv, int root, void* stream);
+/* The same with one count per rank (counts[nranks], identical on every rank): rank r's counts[r] floats land at
+ * d_recv + counts[0] + ... + counts[r-1] on the root, so bands of unequal height -- an output height the rank
+ * count does not divide -- assemble into one contiguous frame.  A count may be 0. */
+int srcnn_comm_gatherv_f32(const float* d_send, const size_t* counts, float* d_recv, int root, void* stream);
 int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, void* stream);
 int srcnn_comm_barrier(void* stream);
 

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -59,21 +60,50 @@ const uint32_t kWeightBits[kWeightCount] = {
 #include "srcnn_weights.inc"
 };
 
-struct DeviceTable {
+struct DeviceTable {          // one uploaded AxisTable; freed only when the last reference goes
     int* first = nullptr;
     int* taps = nullptr;
     double* weight = nullptr;
     int stride = 0;
     int max_taps = 0;
+    unsigned long long stamp = 0;      // LRU clock of the cache
+    DeviceTable() = default;
+    DeviceTable(const DeviceTable&) = delete;
+    DeviceTable& operator=(const DeviceTable&) = delete;
+    ~DeviceTable() { (void)hipFree(first); (void)hipFree(taps); (void)hipFree(weight); }
     DevAxisTable view() const { return DevAxisTable{first, taps, weight, stride, max_taps}; }
 };
+using TableRef = std::shared_ptr<DeviceTable>;
 
-struct Workspace {          // scratch of one stream; grow-only
+struct Workspace {          // scratch of one stream / graph / ProcessSRCNN lane; grow-only
+    std::mutex mu;          // held while a call enqueues work that uses this scratch
     float* tmp = nullptr;   size_t tmp_n = 0;    // first resampler pass
     float* up = nullptr;    size_t up_n = 0;     // upscaled Y (band)
     float* c2 = nullptr;    size_t c2_n = 0;     // 32 layer-2 planes (band)
     float* planes = nullptr; size_t planes_n = 0; // colour shell: split + resized chroma planes
     unsigned char* bytes = nullptr; size_t bytes_n = 0;
+    bool frozen = false;    // a captured graph has these pointers baked in: growing is an error
+    void release()
+    {
+        (void)hipFree(tmp); (void)hipFree(up); (void)hipFree(c2); (void)hipFree(planes); (void)hipFree(bytes);
+        tmp = up = c2 = planes = nullptr; bytes = nullptr;
+        tmp_n = up_n = c2_n = planes_n = bytes_n = 0;
+    }
+};
+
+// One invocation of the path: where it runs, on which scratch, with which numerics.  The mode is read ONCE at the
+// public entry point, so a concurrent srcnn_set_mode never changes a call half way through, and `timing` is how a
+// graph capture tells the stage timers to stay out (event pairs cannot be timed inside a capture) without touching
+// any process-global setting.  `hold` keeps every contribution table the call launches with referenced: for an
+// eager call until the call returns (the cache itself only frees after a device sync), for a graph until the graph
+// is destroyed.
+struct Call {
+    hipStream_t s = nullptr;
+    Workspace* ws = nullptr;
+    int mode = SRCNN_MODE_STRICT;
+    bool timing = true;
+    std::vector<TableRef>* hold = nullptr;
+    bool strict() const { return mode == SRCNN_MODE_STRICT; }
 };
 
 struct StageSpan { hipEvent_t a, b; int stage; };
@@ -82,37 +112,66 @@ struct StreamSlot {         // one lane of the host-stream path; lives until src
     hipStream_t st = nullptr;
     float* din = nullptr;  size_t din_n = 0;
     float* dout = nullptr; size_t dout_n = 0;
+    Workspace ws;                      // private: the captured graph has its pointers baked in
+    std::vector<TableRef> tables;      // ... and these tables
     hipGraphExec_t exec = nullptr;     // captured kernel sequence for (gw, gh, gmode)
     unsigned gw = 0, gh = 0; int gmode = -1;
     unsigned uses = 0;                 // eager runs at the current shape (capture needs one first)
 };
 
+// One lane of srcnn_process_u8 (the ProcessSRCNN surface).  The reference's ProcessSRCNN allocates everything per
+// call and is therefore re-entrant (src/libsrcnn.cpp:628-923); here a call leases a lane -- its own compute and
+// copy streams, scratch, page-locked staging and events -- for its whole duration, so concurrent calls from several
+// host threads never share a buffer.  Lanes are created on demand up to kMaxLanes; further callers wait for one.
+struct ProcLane {
+    bool busy = false;
+    hipStream_t st = nullptr, copy_st = nullptr;
+    Workspace ws;
+    unsigned char* pin_in = nullptr;  size_t pin_in_n = 0;
+    unsigned char* pin_out = nullptr; size_t pin_out_n = 0;
+    std::vector<hipEvent_t> band_events;
+    void release()
+    {
+        ws.release();
+        if (pin_in) (void)hipHostFree(pin_in);
+        if (pin_out) (void)hipHostFree(pin_out);
+        pin_in = pin_out = nullptr; pin_in_n = pin_out_n = 0;
+        for (auto e : band_events) (void)hipEventDestroy(e);
+        band_events.clear();
+        if (st) (void)hipStreamDestroy(st);
+        if (copy_st) (void)hipStreamDestroy(copy_st);
+        st = copy_st = nullptr;
+    }
+};
+constexpr size_t kMaxLanes = 4;
+constexpr size_t kMaxTables = 64;      // cache bound; only unreferenced tables are ever evicted
+
 struct Context {
     std::mutex mu;
-    bool profiling = false;
+    std::atomic<bool> profiling{false};
     std::vector<StageSpan> spans;          // recorded, not yet read
     std::vector<hipEvent_t> event_pool;    // recycled events
     double stage_ms[SRCNN_STAGE_COUNT] = {0, 0, 0};
     unsigned long long stage_n[SRCNN_STAGE_COUNT] = {0, 0, 0};
     bool ready = false;
     int device = 0;
-    int mode = SRCNN_MODE_STRICT;
+    std::atomic<int> mode{SRCNN_MODE_STRICT};
     int num_cus = 256;
     int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
-    std::map<std::tuple<int, unsigned, unsigned>, DeviceTable> tables;
-    std::map<hipStream_t, Workspace> ws;
+    std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
+    unsigned long long table_clock = 0;
+    std::map<hipStream_t, std::unique_ptr<Workspace>> ws;
     StreamSlot slots[2];
-    // srcnn_process_u8 (the ProcessSRCNN surface): page-locked staging + a copy stream, grow-only
-    unsigned char* pin_in = nullptr;  size_t pin_in_n = 0;
-    unsigned char* pin_out = nullptr; size_t pin_out_n = 0;
-    hipStream_t copy_stream = nullptr;
-    std::vector<hipEvent_t> band_events;
-    std::mutex process_mu;
     std::mutex stream_mu;               // srcnn_y_upscale2x_f32_stream is serialised
+    std::mutex lane_mu;                 // ProcessSRCNN lanes
+    std::condition_variable lane_cv;
+    std::vector<std::unique_ptr<ProcLane>> lanes;
 };
 
-Context g;
+// Never destroyed: at process exit the HIP runtime may already be gone when static destructors run, and the
+// tables' destructors call hipFree.  srcnn_shutdown() is the orderly way to release everything.
+Context& g = *new Context;
 
 void build_dev_weights(DevWeights& d)
 {
@@ -201,39 +260,62 @@ int grow(T*& p, size_t& have, size_t want)
     return SRCNN_OK;
 }
 
-int get_table(int filter, unsigned dst_len, unsigned src_len, DeviceTable& out)
+template <class T>
+int grow_ws(Workspace& ws, T*& p, size_t& have, size_t want)
+{
+    if (want <= have) return SRCNN_OK;
+    if (ws.frozen) return fail(SRCNN_E_ARG, "workspace of a captured graph cannot grow (%zu > %zu elements)", want, have);
+    return grow(p, have, want);
+}
+
+// Look up / build / upload the contribution table of one axis.  The cache holds one reference, the caller gets
+// another (and parks it in c.hold), and a table is only ever freed when nobody but the cache references it: a
+// lookup can therefore never invalidate a table handed out earlier -- not the first of the two tables of a
+// resample, not one another thread is about to launch with, not one baked into a captured graph.
+int get_table(Call& c, int filter, unsigned dst_len, unsigned src_len, TableRef& out)
 {
     std::lock_guard<std::mutex> lk(g.mu);
-    auto key = std::make_tuple(filter, dst_len, src_len);
+    const auto key = std::make_tuple(filter, dst_len, src_len);
     auto it = g.tables.find(key);
-    if (it != g.tables.end()) { out = it->second; return SRCNN_OK; }
-    const AxisTable t = build_axis_table(filter, dst_len, src_len);
-    DeviceTable d;
-    d.stride = t.stride;
-    d.max_taps = t.max_taps;
-    HIP_TRY(hipMalloc((void**)&d.first, sizeof(int) * dst_len));
-    HIP_TRY(hipMalloc((void**)&d.taps, sizeof(int) * dst_len));
-    HIP_TRY(hipMalloc((void**)&d.weight, sizeof(double) * t.weight.size()));
-    HIP_TRY(hipMemcpy(d.first, t.first.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d.taps, t.taps.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d.weight, t.weight.data(), sizeof(double) * t.weight.size(), hipMemcpyHostToDevice));
-    if (g.tables.size() > 64) {   // bounded cache: drop everything (tables are cheap to rebuild)
-        hipDeviceSynchronize();
-        for (auto& kv : g.tables) { hipFree(kv.second.first); hipFree(kv.second.taps); hipFree(kv.second.weight); }
-        g.tables.clear();
+    if (it == g.tables.end()) {
+        const AxisTable t = build_axis_table(filter, dst_len, src_len);
+        auto d = std::make_shared<DeviceTable>();
+        d->stride = t.stride;
+        d->max_taps = t.max_taps;
+        HIP_TRY(hipMalloc((void**)&d->first, sizeof(int) * dst_len));
+        HIP_TRY(hipMalloc((void**)&d->taps, sizeof(int) * dst_len));
+        HIP_TRY(hipMalloc((void**)&d->weight, sizeof(double) * t.weight.size()));
+        HIP_TRY(hipMemcpy(d->first, t.first.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->taps, t.taps.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d->weight, t.weight.data(), sizeof(double) * t.weight.size(), hipMemcpyHostToDevice));
+        if (g.tables.size() >= kMaxTables) {
+            // evict the least recently used tables that only the cache still references, down to half the bound.
+            // Kernels launched by calls that already returned may still be reading them, hence the drain first.
+            std::vector<std::pair<unsigned long long, std::tuple<int, unsigned, unsigned>>> idle;
+            for (auto& kv : g.tables)
+                if (kv.second.use_count() == 1) idle.emplace_back(kv.second->stamp, kv.first);
+            std::sort(idle.begin(), idle.end());
+            if (!idle.empty()) (void)hipDeviceSynchronize();
+            for (auto& e : idle) {
+                if (g.tables.size() < kMaxTables / 2) break;
+                g.tables.erase(e.second);
+            }
+        }
+        it = g.tables.emplace(key, std::move(d)).first;
     }
-    g.tables[key] = d;
-    out = d;
+    it->second->stamp = ++g.table_clock;
+    out = it->second;
+    if (c.hold) c.hold->push_back(out);
     return SRCNN_OK;
 }
 
-Workspace& workspace_for(hipStream_t s)
+Workspace* workspace_for(hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g.mu);
-    return g.ws[s];
+    auto& p = g.ws[s];
+    if (!p) p = std::make_unique<Workspace>();
+    return p.get();
 }
-
-bool strict_mode() { return g.mode == SRCNN_MODE_STRICT; }
 
 // RAII bracket: records an event pair around one stage on the launch stream when profiling is on.
 struct StageTimer {
@@ -245,7 +327,7 @@ struct StageTimer {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
-    StageTimer(int stage_, hipStream_t s_) : s(s_), stage(stage_), on(g.profiling)
+    StageTimer(int stage_, const Call& c) : s(c.s), stage(stage_), on(c.timing && g.profiling.load(std::memory_order_relaxed))
     {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g.mu);
@@ -278,12 +360,12 @@ void drain_spans_locked()
 
 // Y holds rows [y_row_base, y_row_base + y_rows) of the (W x H) upscaled plane; the kernels clamp their halo
 // reads to that range as well as to the image (tile rows past the end of a band are computed but never stored).
-void run_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane, int row0, int rows,
-                hipStream_t s)
+void run_conv12(const Call& c, const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane, int row0,
+                int rows)
 {
-    if (g.mode == SRCNN_MODE_FAST_F16) launch_conv12_f16(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, g.num_cus, s);
-    else if (g.conv12_valu) launch_conv12(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, strict_mode(), s);
-    else launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, strict_mode(), g.num_cus, g.conv12_variant, s);
+    if (c.mode == SRCNN_MODE_FAST_F16) launch_conv12_f16(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, g.num_cus, c.s);
+    else if (g.conv12_valu) launch_conv12(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.s);
+    else launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), g.num_cus, g.conv12_variant, c.s);
 }
 
 int check_plane(const void* in, unsigned w, unsigned h, const void* out)
@@ -294,10 +376,12 @@ int check_plane(const void* in, unsigned w, unsigned h, const void* out)
 }
 
 // FRAWResizeEngine::scale (src/frawscale.cpp:162-286) for destination rows [r0,r1) only.
-// dst holds rows [r0,r1) (row r0 at offset 0).  tmp is scratch from the workspace.
-int resample_rows_range(const float* d_in, unsigned sw, unsigned sh, unsigned dw, unsigned dh, int filter,
-                        unsigned r0, unsigned r1, float* d_dst, Workspace& ws, hipStream_t s)
+// dst holds rows [r0,r1) (row r0 at offset 0).  tmp is scratch from the call's workspace.
+int resample_rows_range(Call& c, const float* d_in, unsigned sw, unsigned sh, unsigned dw, unsigned dh, int filter,
+                        unsigned r0, unsigned r1, float* d_dst)
 {
+    Workspace& ws = *c.ws;
+    hipStream_t s = c.s;
     if (sw == dw && sh == dh) {
         // The reference's identity branch copies sizeof(unsigned short) bytes per pixel into an
         // uninitialised buffer (src/frawscale.cpp:185-193), i.e. half the plane is garbage.  We copy the
@@ -306,71 +390,117 @@ int resample_rows_range(const float* d_in, unsigned sw, unsigned sh, unsigned dw
                                hipMemcpyDeviceToDevice, s));
         return SRCNN_OK;
     }
-    DeviceTable tv, th;
+    TableRef tv, th;
     int rc;
     if (dw <= sw) {
         // horizontal first over all source rows, then vertical (src/frawscale.cpp:195-237)
         const float* mid = d_in;
         if (sw != dw) {
-            if ((rc = get_table(filter, dw, sw, th))) return rc;
+            if ((rc = get_table(c, filter, dw, sw, th))) return rc;
             if (sh != dh) {
-                if ((rc = grow(ws.tmp, ws.tmp_n, (size_t)dw * sh))) return rc;
-                launch_resample_rows(d_in, sw, ws.tmp, dw, sh, th.view(), s);
+                if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)dw * sh))) return rc;
+                launch_resample_rows(d_in, sw, ws.tmp, dw, sh, th->view(), s);
                 mid = ws.tmp;
             } else {
-                launch_resample_rows(d_in + (size_t)r0 * sw, sw, d_dst, dw, r1 - r0, th.view(), s);
+                launch_resample_rows(d_in + (size_t)r0 * sw, sw, d_dst, dw, r1 - r0, th->view(), s);
                 return SRCNN_OK;
             }
         }
-        if ((rc = get_table(filter, dh, sh, tv))) return rc;
-        launch_resample_cols(mid, dw, 0, d_dst, r0, r1 - r0, tv.view(), s);
+        if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
+        launch_resample_cols(mid, dw, 0, d_dst, r0, r1 - r0, tv->view(), s);
     } else {
         // vertical first, then horizontal (src/frawscale.cpp:238-278)
-        if ((rc = get_table(filter, dw, sw, th))) return rc;
+        if ((rc = get_table(c, filter, dw, sw, th))) return rc;
         const float* mid = d_in + (size_t)r0 * sw;
         if (sh != dh) {
-            if ((rc = get_table(filter, dh, sh, tv))) return rc;
-            if ((rc = grow(ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
-            launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, tv.view(), s);
+            if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
+            if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
+            launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, tv->view(), s);
             mid = ws.tmp;
         }
-        launch_resample_rows(mid, sw, d_dst, dw, r1 - r0, th.view(), s);
+        launch_resample_rows(mid, sw, d_dst, dw, r1 - r0, th->view(), s);
     }
     return SRCNN_OK;
 }
 
 // resample + conv12 + conv3 for output rows [r0,r1) of the (dw x dh) result.
-int y_path_rows(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
-                unsigned r0, unsigned r1, float* d_out, hipStream_t s)
+int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+                unsigned r0, unsigned r1, float* d_out)
 {
     if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
     if (dh > (1u << 20) || h > (1u << 20) || dw > 0x7fffffu || (r1 - r0) > 65535u * 16u)
         return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large", dw, dh);
-    Workspace& ws = workspace_for(s);
+    Workspace& ws = *c.ws;
     // rows of layer-2 activations that conv3 touches (clamp-to-edge of the ACTIVATIONS at the true
     // border), and rows of upscaled Y that conv1 touches for those.
     const unsigned ca = r0 >= 2 ? r0 - 2 : 0, cb = std::min(dh, r1 + 2);
     const unsigned ua = ca >= 4 ? ca - 4 : 0, ub = std::min(dh, cb + 4);
     int rc;
-    if ((rc = grow(ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
-    if ((rc = grow(ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
+    if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
+    if ((rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
     {
-        StageTimer t(SRCNN_STAGE_RESAMPLE, s);
-        if ((rc = resample_rows_range(d_in, w, h, dw, dh, filter, ua, ub, ws.up, ws, s))) return rc;
+        StageTimer t(SRCNN_STAGE_RESAMPLE, c);
+        if ((rc = resample_rows_range(c, d_in, w, h, dw, dh, filter, ua, ub, ws.up))) return rc;
     }
     const size_t plane = (size_t)dw * (cb - ca);
     {
-        StageTimer t(SRCNN_STAGE_CONV12, s);
-        run_conv12(ws.up, (int)dw, (int)dh, (int)ua, (int)(ub - ua), ws.c2, plane, (int)ca, (int)(cb - ca), s);
+        StageTimer t(SRCNN_STAGE_CONV12, c);
+        run_conv12(c, ws.up, (int)dw, (int)dh, (int)ua, (int)(ub - ua), ws.c2, plane, (int)ca, (int)(cb - ca));
     }
     {
-        StageTimer t(SRCNN_STAGE_CONV3, s);
+        StageTimer t(SRCNN_STAGE_CONV3, c);
         launch_conv3(ws.c2, plane, (int)dw, (int)dh, (int)ca, (int)(cb - ca), d_out, (int)r0, (int)(r1 - r0),
-                     strict_mode(), s);
+                     c.strict(), c.s);
     }
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }
+
+// One whole frame.  The 32 layer-2 planes are the big scratch (128 B per output pixel).  Frames whose planes would
+// exceed the workspace budget (default 16 GiB, SRCNN_MAX_WORKSPACE_MB) are produced in horizontal bands --
+// bit-identical to the whole frame -- so a 16K x 16K output needs the same scratch as an 8K one.
+int y_path_frame(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* d_out)
+{
+    static const size_t budget = [] {
+        const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
+        const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
+        return std::max<size_t>(mb, 1) << 20;
+    }();
+    const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
+    if (row_bytes * dh <= budget) return y_path_rows(c, d_in, w, h, dw, dh, filter, 0, dh, d_out);
+    const size_t fit = budget / row_bytes;
+    const unsigned band = (unsigned)std::max<size_t>(16, fit > 4 ? fit - 4 : 1);
+    for (unsigned r0 = 0; r0 < dh; r0 += band) {
+        const unsigned r1 = std::min(dh, r0 + band);
+        int rc = y_path_rows(c, d_in, w, h, dw, dh, filter, r0, r1, d_out + (size_t)r0 * dw);
+        if (rc) return rc;
+    }
+    return SRCNN_OK;
+}
+
+int check_y_path_args(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, const float* d_out)
+{
+    int rc = check_plane(d_in, w, h, d_out);
+    if (rc) return rc;
+    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
+    return SRCNN_OK;
+}
+
+// An eager call on a caller-visible stream: the stream's own scratch, locked while this call enqueues.
+struct StreamCall {
+    std::vector<TableRef> tables;
+    Call c;
+    std::unique_lock<std::mutex> lk;
+    explicit StreamCall(void* stream)
+    {
+        c.s = (hipStream_t)stream;
+        c.ws = workspace_for(c.s);
+        c.mode = g.mode.load();
+        c.hold = &tables;
+        lk = std::unique_lock<std::mutex>(c.ws->mu);
+    }
+};
 
 int grow_pinned(unsigned char*& p, size_t& have, size_t want)
 {
@@ -401,6 +531,44 @@ void parallel_memcpy(void* dst, const void* src, size_t n)
     for (auto& t : th) t.join();
 }
 
+// Lease of one ProcessSRCNN lane for the duration of a call.
+struct LaneLease {
+    ProcLane* lane = nullptr;
+    int rc = SRCNN_OK;
+    LaneLease()
+    {
+        std::unique_lock<std::mutex> lk(g.lane_mu);
+        for (;;) {
+            for (auto& l : g.lanes)
+                if (!l->busy) { lane = l.get(); break; }
+            if (lane) break;
+            if (g.lanes.size() < kMaxLanes) {
+                auto l = std::make_unique<ProcLane>();
+                if (hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking) != hipSuccess ||
+                    hipStreamCreateWithFlags(&l->copy_st, hipStreamNonBlocking) != hipSuccess) {
+                    l->release();
+                    rc = fail(SRCNN_E_HIP, "could not create the streams of a ProcessSRCNN lane");
+                    return;
+                }
+                g.lanes.push_back(std::move(l));
+                lane = g.lanes.back().get();
+                break;
+            }
+            g.lane_cv.wait(lk);
+        }
+        lane->busy = true;
+    }
+    ~LaneLease()
+    {
+        if (!lane) return;
+        // nothing of this call may still be running on the lane when the next caller takes it
+        (void)hipStreamSynchronize(lane->st);
+        (void)hipStreamSynchronize(lane->copy_st);
+        { std::lock_guard<std::mutex> lk(g.lane_mu); lane->busy = false; }
+        g.lane_cv.notify_one();
+    }
+};
+
 }  // namespace
 
 // ================================================================================================
@@ -425,26 +593,28 @@ int srcnn_init(int device)
 
 void srcnn_shutdown(void)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (!g.ready) return;
-    hipDeviceSynchronize();
-    for (auto& kv : g.tables) { hipFree(kv.second.first); hipFree(kv.second.taps); hipFree(kv.second.weight); }
-    g.tables.clear();
-    for (auto& kv : g.ws) {
-        hipFree(kv.second.tmp); hipFree(kv.second.up); hipFree(kv.second.c2);
-        hipFree(kv.second.planes); hipFree(kv.second.bytes);
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (!g.ready) return;
     }
+    (void)hipDeviceSynchronize();
+    {
+        std::lock_guard<std::mutex> lk(g.lane_mu);
+        for (auto& l : g.lanes) l->release();
+        g.lanes.clear();
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.tables.clear();                        // graphs still alive keep their own references
+    for (auto& kv : g.ws) kv.second->release();
     g.ws.clear();
-    if (g.pin_in) { (void)hipHostFree(g.pin_in); g.pin_in = nullptr; g.pin_in_n = 0; }
-    if (g.pin_out) { (void)hipHostFree(g.pin_out); g.pin_out = nullptr; g.pin_out_n = 0; }
-    if (g.copy_stream) { (void)hipStreamDestroy(g.copy_stream); g.copy_stream = nullptr; }
-    for (auto e : g.band_events) (void)hipEventDestroy(e);
-    g.band_events.clear();
     for (auto& sl : g.slots) {
         if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
         if (sl.st) (void)hipStreamDestroy(sl.st);
         (void)hipFree(sl.din); (void)hipFree(sl.dout);
-        sl = StreamSlot();
+        sl.ws.release();
+        sl.tables.clear();
+        sl.st = nullptr; sl.din = sl.dout = nullptr; sl.din_n = sl.dout_n = 0;
+        sl.exec = nullptr; sl.gw = sl.gh = 0; sl.gmode = -1; sl.uses = 0;
     }
     g.ready = false;
 }
@@ -452,13 +622,10 @@ void srcnn_shutdown(void)
 int srcnn_set_mode(int mode)
 {
     if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST && mode != SRCNN_MODE_FAST_F16) return fail(SRCNN_E_ARG, "bad mode %d", mode);
-    std::lock_guard<std::mutex> lk(g.mu);
-    const int prev = g.mode;
-    g.mode = mode;
-    return prev;
+    return g.mode.exchange(mode);
 }
 
-int srcnn_get_mode(void) { return g.mode; }
+int srcnn_get_mode(void) { return g.mode.load(); }
 
 int srcnn_device_name(char* buf, size_t cap)
 {
@@ -520,15 +687,13 @@ int srcnn_stream_destroy(void* stream)
 {
     if (!stream) return SRCNN_OK;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::unique_ptr<Workspace> ws;
     {
         std::lock_guard<std::mutex> lk(g.mu);
         auto it = g.ws.find((hipStream_t)stream);
-        if (it != g.ws.end()) {
-            hipFree(it->second.tmp); hipFree(it->second.up); hipFree(it->second.c2);
-            hipFree(it->second.planes); hipFree(it->second.bytes);
-            g.ws.erase(it);
-        }
+        if (it != g.ws.end()) { ws = std::move(it->second); g.ws.erase(it); }
     }
+    if (ws) { std::lock_guard<std::mutex> wl(ws->mu); ws->release(); }
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return SRCNN_OK;
 }
@@ -553,26 +718,9 @@ int srcnn_y_path_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw,
                          float* d_out, void* stream)
 {
     int rc = ensure_init(); if (rc) return rc;
-    if ((rc = check_plane(d_in, w, h, d_out))) return rc;
-    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
-    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
-    // The 32 layer-2 planes are the big scratch (128 B per output pixel).  Frames whose planes would exceed the
-    // workspace budget (default 16 GiB, SRCNN_MAX_WORKSPACE_MB) are produced in horizontal bands -- bit-identical
-    // to the whole frame -- so a 16K x 16K output needs the same scratch as an 8K one.
-    static const size_t budget = [] {
-        const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
-        const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
-        return std::max<size_t>(mb, 1) << 20;
-    }();
-    const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
-    if (row_bytes * dh <= budget) return y_path_rows(d_in, w, h, dw, dh, filter, 0, dh, d_out, (hipStream_t)stream);
-    const size_t fit = budget / row_bytes;
-    const unsigned band = (unsigned)std::max<size_t>(16, fit > 4 ? fit - 4 : 1);
-    for (unsigned r0 = 0; r0 < dh; r0 += band) {
-        const unsigned r1 = std::min(dh, r0 + band);
-        if ((rc = y_path_rows(d_in, w, h, dw, dh, filter, r0, r1, d_out + (size_t)r0 * dw, (hipStream_t)stream))) return rc;
-    }
-    return SRCNN_OK;
+    if ((rc = check_y_path_args(d_in, w, h, dw, dh, filter, d_out))) return rc;
+    StreamCall sc(stream);
+    return y_path_frame(sc.c, d_in, w, h, dw, dh, filter, d_out);
 }
 
 int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_out, void* stream)
@@ -580,44 +728,70 @@ int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* 
     return srcnn_y_path_f32_dev(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out, stream);
 }
 
-int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out,
-                                    void* stream)
+namespace {
+int batch_frames(Call& c, const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out)
 {
-    if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
     const size_t in_n = (size_t)w * h, out_n = in_n * 4;
     for (unsigned f = 0; f < nframes; ++f) {
-        int rc = srcnn_y_upscale2x_f32_dev(d_in + f * in_n, w, h, d_out + f * out_n, stream);
+        int rc = y_path_frame(c, d_in + f * in_n, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out + f * out_n);
         if (rc) return rc;
     }
     return SRCNN_OK;
 }
+}  // namespace
 
-namespace { struct BatchGraph { hipGraphExec_t exec; hipStream_t stream; }; }
+int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out,
+                                    void* stream)
+{
+    if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_y_path_args(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out))) return rc;
+    StreamCall sc(stream);
+    return batch_frames(sc.c, d_in, w, h, nframes, d_out);
+}
+
+namespace {
+// A captured batch owns everything its kernel nodes point at: its scratch and its contribution tables live exactly
+// as long as the handle, whatever happens to the stream's own workspace or to the table cache in the meantime.
+struct BatchGraph {
+    hipGraphExec_t exec = nullptr;
+    hipStream_t stream = nullptr;
+    Workspace ws;
+    std::vector<TableRef> tables;
+};
+}  // namespace
 
 int srcnn_batch_graph_create(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out, void* stream,
                              void** graph)
 {
     if (!graph) return fail(SRCNN_E_ARG, "graph == NULL");
     if (!stream) return fail(SRCNN_E_ARG, "graph capture needs a non-default stream");
-    hipStream_t s = (hipStream_t)stream;
-    // eager run first: builds tables and grows the workspace, so nothing allocates inside the capture
-    int rc = srcnn_y_upscale2x_f32_batch_dev(d_in, w, h, nframes, d_out, stream);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s));
-    const bool was_profiling = g.profiling;
-    g.profiling = false;                                   // event pairs cannot be timed inside a capture
+    if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_y_path_args(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out))) return rc;
+    auto bg = std::make_unique<BatchGraph>();
+    bg->stream = (hipStream_t)stream;
+    Call c;
+    c.s = bg->stream; c.ws = &bg->ws; c.mode = g.mode.load(); c.hold = &bg->tables;
+    auto drop = [&](int code) { (void)hipStreamSynchronize(bg->stream); bg->ws.release(); return code; };
+    // eager run first: builds tables and grows the private workspace, so nothing allocates inside the capture
+    if ((rc = batch_frames(c, d_in, w, h, nframes, d_out))) return drop(rc);
+    if (hipStreamSynchronize(bg->stream) != hipSuccess) return drop(fail(SRCNN_E_HIP, "stream sync before capture failed"));
+    bg->ws.frozen = true;
+    c.timing = false;                                      // event pairs cannot be timed inside a capture
     hipGraph_t gr = nullptr;
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) rc = srcnn_y_upscale2x_f32_batch_dev(d_in, w, h, nframes, d_out, stream);
-    hipError_t e2 = hipStreamEndCapture(s, &gr);
-    g.profiling = was_profiling;
-    if (e != hipSuccess || e2 != hipSuccess) return fail(SRCNN_E_HIP, "stream capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-    if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
-    hipGraphExec_t exec = nullptr;
-    e = hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0);
+    hipError_t e = hipStreamBeginCapture(bg->stream, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) rc = batch_frames(c, d_in, w, h, nframes, d_out);
+    hipError_t e2 = hipStreamEndCapture(bg->stream, &gr);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        if (gr) (void)hipGraphDestroy(gr);
+        return drop(fail(SRCNN_E_HIP, "stream capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2)));
+    }
+    if (rc) { if (gr) (void)hipGraphDestroy(gr); return drop(rc); }
+    e = hipGraphInstantiate(&bg->exec, gr, nullptr, nullptr, 0);
     (void)hipGraphDestroy(gr);
-    if (e != hipSuccess) return fail(SRCNN_E_HIP, "hipGraphInstantiate -> %s", hipGetErrorString(e));
-    *graph = new BatchGraph{exec, s};
+    if (e != hipSuccess) return drop(fail(SRCNN_E_HIP, "hipGraphInstantiate -> %s", hipGetErrorString(e)));
+    *graph = bg.release();
     return SRCNN_OK;
 }
 
@@ -635,6 +809,7 @@ int srcnn_batch_graph_destroy(void* graph)
     BatchGraph* b = static_cast<BatchGraph*>(graph);
     (void)hipStreamSynchronize(b->stream);
     (void)hipGraphExecDestroy(b->exec);
+    b->ws.release();
     delete b;
     return SRCNN_OK;
 }
@@ -645,18 +820,13 @@ int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h, un
     int rc = ensure_init(); if (rc) return rc;
     if ((rc = check_plane(d_in, w, h, d_out_band))) return rc;
     if (rows == 0) return fail(SRCNN_E_ARG, "rows == 0");
-    return y_path_rows(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, row0, row0 + rows, d_out_band,
-                       (hipStream_t)stream);
+    if ((unsigned long long)row0 + rows > 2ull * h) return fail(SRCNN_E_ARG, "band [%u,+%u) outside the %u output rows", row0, rows, 2 * h);
+    StreamCall sc(stream);
+    return y_path_rows(sc.c, d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, row0, row0 + rows, d_out_band);
 }
 
 // ---- per-kernel timing -------------------------------------------------------------------------
-int srcnn_profile_enable(int on)
-{
-    std::lock_guard<std::mutex> lk(g.mu);
-    const int prev = g.profiling ? 1 : 0;
-    g.profiling = on != 0;
-    return prev;
-}
+int srcnn_profile_enable(int on) { return g.profiling.exchange(on != 0) ? 1 : 0; }
 
 int srcnn_profile_reset(void)
 {
@@ -681,12 +851,10 @@ int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned d
                            float* d_out, void* stream)
 {
     int rc = ensure_init(); if (rc) return rc;
-    if ((rc = check_plane(d_in, w, h, d_out))) return rc;
-    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
-    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
+    if ((rc = check_y_path_args(d_in, w, h, dw, dh, filter, d_out))) return rc;
     if (dh > (1u << 20) || h > (1u << 20)) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
-    Workspace& ws = workspace_for((hipStream_t)stream);
-    rc = resample_rows_range(d_in, w, h, dw, dh, filter, 0, dh, d_out, ws, (hipStream_t)stream);
+    StreamCall sc(stream);
+    rc = resample_rows_range(sc.c, d_in, w, h, dw, dh, filter, 0, dh, d_out);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
@@ -716,7 +884,8 @@ int srcnn_conv3_f32_dev(const float* d_c2, unsigned w, unsigned h, float* d_out,
     int rc = ensure_init(); if (rc) return rc;
     if ((rc = check_plane(d_c2, w, h, d_out))) return rc;
     if (h > 65535u * 16u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
-    launch_conv3(d_c2, (size_t)w * h, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, strict_mode(), (hipStream_t)stream);
+    launch_conv3(d_c2, (size_t)w * h, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, g.mode.load() == SRCNN_MODE_STRICT,
+                 (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }
@@ -726,7 +895,9 @@ int srcnn_conv12_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c2, 
     int rc = ensure_init(); if (rc) return rc;
     if ((rc = check_plane(d_y, w, h, d_c2))) return rc;
     if (h > 65535u * 4u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
-    run_conv12(d_y, (int)w, (int)h, 0, (int)h, d_c2, (size_t)w * h, 0, (int)h, (hipStream_t)stream);
+    Call c;
+    c.s = (hipStream_t)stream; c.mode = g.mode.load();
+    run_conv12(c, d_y, (int)w, (int)h, 0, (int)h, d_c2, (size_t)w * h, 0, (int)h);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }
@@ -763,6 +934,7 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
     if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
     const size_t in_n = (size_t)w * h, out_n = in_n * 4;
     const size_t in_b = in_n * sizeof(float), out_b = out_n * sizeof(float);
+    const int mode = g.mode.load();
 
     // page-lock the caller's frames so the copies are truly asynchronous; harmless if it fails
     const bool reg_in = hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterDefault) == hipSuccess;
@@ -774,34 +946,39 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
     for (int i = 0; i < nslots && !rc; ++i) {
         StreamSlot& sl = g.slots[i];
         if (!sl.st && hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
+        if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) {     // shape or mode changed: drop the graph first,
+            if (sl.exec) { (void)hipStreamSynchronize(sl.st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
+            sl.ws.frozen = false;                                          // then its buffers may move again
+            sl.tables.clear();
+            sl.gw = w; sl.gh = h; sl.gmode = mode; sl.uses = 0;
+        }
         if (!rc) rc = grow(sl.din, sl.din_n, in_n);
         if (!rc) rc = grow(sl.dout, sl.dout_n, out_n);
-        if (sl.exec && (sl.gw != w || sl.gh != h || sl.gmode != g.mode)) {     // shape or mode changed: drop the graph
-            (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; sl.uses = 0;
-        }
-        if (sl.gw != w || sl.gh != h || sl.gmode != g.mode) { sl.gw = w; sl.gh = h; sl.gmode = g.mode; sl.uses = 0; }
     }
-    const bool was_profiling = g.profiling;
     for (unsigned f = 0; f < nframes && !rc; ++f) {
         StreamSlot& sl = g.slots[f % nslots];
+        Call c;
+        c.s = sl.st; c.ws = &sl.ws; c.mode = mode; c.hold = &sl.tables;
         if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "H2D"); break; }
         if (use_graph && sl.uses >= 1 && !sl.exec) {
             // The slot has run this shape eagerly once: tables and workspaces exist, so the kernel sequence
             // can be captured without any allocation inside the capture.
             hipGraph_t graph = nullptr;
-            g.profiling = false;           // event pairs cannot be timed inside a capture
+            sl.ws.frozen = true;
+            c.timing = false;              // event pairs cannot be timed inside a capture
             if (hipStreamBeginCapture(sl.st, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
-            if (!rc) rc = srcnn_y_upscale2x_f32_dev(sl.din, w, h, sl.dout, sl.st);
+            if (!rc) rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
             if (hipStreamEndCapture(sl.st, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
-            g.profiling = was_profiling;
+            c.timing = true;
             if (!rc && hipGraphInstantiate(&sl.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(SRCNN_E_HIP, "graph instantiate");
             if (graph) (void)hipGraphDestroy(graph);
-            if (rc) break;
+            if (rc) { sl.ws.frozen = false; break; }
         }
         if (use_graph && sl.exec) {
             if (hipGraphLaunch(sl.exec, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
         } else {
-            rc = srcnn_y_upscale2x_f32_dev(sl.din, w, h, sl.dout, sl.st);
+            if (sl.tables.size() > 16) sl.tables.clear();   // eager runs re-take their references every frame
+            rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
             if (rc) break;
         }
         if (hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
@@ -829,12 +1006,24 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     int rc = ensure_init(); if (rc) return rc;
     const unsigned dw = (unsigned)((float)w * multiply), dh = (unsigned)((float)h * multiply);   // src/libsrcnn.cpp:662-663
     if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    if ((unsigned long long)w * h > 0x7fffffffULL || (unsigned long long)dw * dh > 0x7fffffffULL)
+        return fail(SRCNN_E_UNSUPPORTED, "plane too large");
     const size_t n = (size_t)w * h, dn = (size_t)dw * dh;
-    hipStream_t s = nullptr;
-    Workspace& ws = workspace_for(s);
+
+    // Everything below runs on a lane leased for this call only (see ProcLane): concurrent ProcessSRCNN calls from
+    // several host threads are independent, like the reference's.
+    LaneLease lease;
+    if (lease.rc) return lease.rc;
+    ProcLane& L = *lease.lane;
+    Workspace& ws = L.ws;
+    hipStream_t s = L.st;
+    std::vector<TableRef> tables;
+    Call c;
+    c.s = s; c.ws = &ws; c.mode = g.mode.load(); c.hold = &tables;
+
     // planes: [Y Cb Cr A] at source size, then [Y' Cb' Cr' A'] at destination size
-    if ((rc = grow(ws.planes, ws.planes_n, 4 * n + 4 * dn))) return rc;
-    if ((rc = grow(ws.bytes, ws.bytes_n, n * d + dn * d + dn))) return rc;
+    if ((rc = grow_ws(ws, ws.planes, ws.planes_n, 4 * n + 4 * dn))) return rc;
+    if ((rc = grow_ws(ws, ws.bytes, ws.bytes_n, n * d + dn * d + dn))) return rc;
     float* sp[4]; float* dp[4];
     for (int k = 0; k < 4; ++k) { sp[k] = ws.planes + k * n; dp[k] = ws.planes + 4 * n + k * dn; }
     unsigned char* d_rgb = ws.bytes; unsigned char* d_out = ws.bytes + n * d; unsigned char* d_conv = d_out + dn * d;
@@ -847,12 +1036,12 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     const size_t out_bytes = dn * d;
 
     if (out_bytes < (8u << 20)) {
-        // small image: one shot on the default stream
+        // small image: one shot on the lane's stream
         HIP_TRY(hipMemcpyAsync(d_rgb, rgb, n * d, hipMemcpyHostToDevice, s));
         launch_rgb_split(d_rgb, n, (int)d, sp[0], sp[1], sp[2], sp[3], s);
         for (unsigned k = 1; k < d; ++k)
-            if ((rc = srcnn_resample_f32_dev(sp[k], w, h, dw, dh, cfilter, dp[k], s))) return rc;
-        if ((rc = srcnn_y_path_f32_dev(sp[0], w, h, dw, dh, filter, dp[0], s))) return rc;
+            if ((rc = resample_rows_range(c, sp[k], w, h, dw, dh, cfilter, 0, dh, dp[k]))) return rc;
+        if ((rc = y_path_frame(c, sp[0], w, h, dw, dh, filter, dp[0]))) return rc;
         launch_ycc_merge(dp[0], dp[1], dp[2], dp[3], dn, (int)d, d_out, conv_opt ? d_conv : nullptr, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
@@ -866,34 +1055,32 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     // page-locked staging on both sides, the output produced in horizontal bands (bit-identical to the whole
     // frame, tests/test_gpu_parity.py::test_bands_equal_whole_frame), each band's D2H on a copy stream while the
     // next band computes, and a helper thread that fans each landed band out to the caller's buffers.
-    std::lock_guard<std::mutex> plk(g.process_mu);
     const auto t0 = now();
-    if ((rc = grow_pinned(g.pin_in, g.pin_in_n, n * d))) return rc;
-    if ((rc = grow_pinned(g.pin_out, g.pin_out_n, out_bytes + dn))) return rc;
-    if (!g.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+    if ((rc = grow_pinned(L.pin_in, L.pin_in_n, n * d))) return rc;
+    if ((rc = grow_pinned(L.pin_out, L.pin_out_n, out_bytes + dn))) return rc;
     const unsigned nb = std::max(1u, std::min(8u, dh / 256u));
-    while (g.band_events.size() < 2 * nb) {
+    while (L.band_events.size() < 2 * nb) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        g.band_events.push_back(e);
+        L.band_events.push_back(e);
     }
-    parallel_memcpy(g.pin_in, rgb, n * d);
-    HIP_TRY(hipMemcpyAsync(d_rgb, g.pin_in, n * d, hipMemcpyHostToDevice, s));
+    parallel_memcpy(L.pin_in, rgb, n * d);
+    HIP_TRY(hipMemcpyAsync(d_rgb, L.pin_in, n * d, hipMemcpyHostToDevice, s));
     launch_rgb_split(d_rgb, n, (int)d, sp[0], sp[1], sp[2], sp[3], s);
     for (unsigned k = 1; k < d; ++k)
-        if ((rc = srcnn_resample_f32_dev(sp[k], w, h, dw, dh, cfilter, dp[k], s))) return rc;
+        if ((rc = resample_rows_range(c, sp[k], w, h, dw, dh, cfilter, 0, dh, dp[k]))) return rc;
     const auto t1 = now();
 
-    unsigned char* pin_rgb = g.pin_out;
-    unsigned char* pin_conv = g.pin_out + out_bytes;
+    unsigned char* pin_rgb = L.pin_out;
+    unsigned char* pin_conv = L.pin_out + out_bytes;
     std::vector<unsigned> r0s(nb + 1);
     unsigned max_band = 0;
     for (unsigned b = 0; b <= nb; ++b) r0s[b] = (unsigned)((unsigned long long)dh * b / nb);
     for (unsigned b = 0; b < nb; ++b) max_band = std::max(max_band, r0s[b + 1] - r0s[b]);
     // size the band scratch once, for the largest band plus its halos, so no band re-allocates mid-pipeline
-    if ((rc = grow(ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
-    if ((rc = grow(ws.up, ws.up_n, (size_t)dw * std::min(dh, max_band + 12)))) return rc;
-    if ((rc = grow(ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
+    if ((rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
+    if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * std::min(dh, max_band + 12)))) return rc;
+    if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
     const int dev = g.device;
     std::atomic<int> copy_err{0};
     std::atomic<unsigned> enqueued{0};      // bands whose "landed" event has been recorded in THIS call
@@ -901,7 +1088,7 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
         (void)hipSetDevice(dev);
         for (unsigned b = 0; b < nb; ++b) {
             while (enqueued.load(std::memory_order_acquire) <= b) std::this_thread::yield();
-            if (hipEventSynchronize(g.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
+            if (hipEventSynchronize(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
             const size_t p0 = (size_t)r0s[b] * dw, p1 = (size_t)r0s[b + 1] * dw;
             parallel_memcpy(out + p0 * d, pin_rgb + p0 * d, (p1 - p0) * d);
             if (conv_opt) parallel_memcpy(conv_opt + p0, pin_conv + p0, p1 - p0);
@@ -911,23 +1098,23 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     for (unsigned b = 0; b < nb; ++b) {
         const unsigned r0 = r0s[b], r1 = r0s[b + 1];
         const size_t p0 = (size_t)r0 * dw, pn = (size_t)(r1 - r0) * dw;
-        if (!launch_rc) launch_rc = y_path_rows(sp[0], w, h, dw, dh, filter, r0, r1, dp[0] + p0, s);
+        if (!launch_rc) launch_rc = y_path_rows(c, sp[0], w, h, dw, dh, filter, r0, r1, dp[0] + p0);
         if (!launch_rc) {
             launch_ycc_merge(dp[0] + p0, dp[1] + p0, dp[2] + p0, dp[3] + p0, pn, (int)d, d_out + p0 * d,
                              conv_opt ? d_conv + p0 : nullptr, s);
-            if (hipEventRecord(g.band_events[2 * b], s) != hipSuccess ||
-                hipStreamWaitEvent(g.copy_stream, g.band_events[2 * b], 0) != hipSuccess ||
-                hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, g.copy_stream) != hipSuccess ||
-                (conv_opt && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, g.copy_stream) != hipSuccess))
+            if (hipEventRecord(L.band_events[2 * b], s) != hipSuccess ||
+                hipStreamWaitEvent(L.copy_st, L.band_events[2 * b], 0) != hipSuccess ||
+                hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
+                (conv_opt && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess))
                 launch_rc = fail(SRCNN_E_HIP, "band %u copy enqueue failed", b);
         }
         // the fan-out thread waits on this event for every band, so it is recorded even after a failure
-        (void)hipEventRecord(g.band_events[2 * b + 1], g.copy_stream);
+        (void)hipEventRecord(L.band_events[2 * b + 1], L.copy_st);
         enqueued.store(b + 1, std::memory_order_release);
     }
     fanout.join();
     const auto t2 = now();
-    hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(g.copy_stream);
+    hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(L.copy_st);
     if (launch_rc) return launch_rc;
     if (e1 != hipSuccess || e2 != hipSuccess || copy_err) return fail(SRCNN_E_HIP, "pipeline failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     HIP_TRY(hipGetLastError());
@@ -945,6 +1132,14 @@ int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, 
     if (right) memcpy(right, t.last.data(), sizeof(int) * dst_len);
     if (weights) memcpy(weights, t.weight.data(), sizeof(double) * t.weight.size());
     return t.window;
+}
+
+// test hook: number of cached contribution tables / of ProcessSRCNN lanes created so far
+int srcnn_debug_counts(int* tables, int* lanes)
+{
+    { std::lock_guard<std::mutex> lk(g.mu); if (tables) *tables = (int)g.tables.size(); }
+    { std::lock_guard<std::mutex> lk(g.lane_mu); if (lanes) *lanes = (int)g.lanes.size(); }
+    return SRCNN_OK;
 }
 
 }  // extern "C"

@@ -45,17 +45,35 @@ int load()
 {
     if (R.h) return 0;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) { R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
-    if (!R.h) {
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) {
         snprintf(g_cerr, sizeof g_cerr, "dlopen(librccl) failed: %s", dlerror());
         srcnn::set_last_error(g_cerr);
         return SRCNN_E_COMM;
     }
-#define SYM(f) R.f = reinterpret_cast<decltype(R.f)>(dlsym(R.h, "nccl" #f)); if (!R.f) { snprintf(g_cerr, sizeof g_cerr, "missing nccl" #f); return SRCNN_E_COMM; }
+    Rccl r;
+    const char* missing = nullptr;
+#define SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(h, "nccl" #f)); if (!r.f && !missing) missing = "nccl" #f;
     SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(GroupStart) SYM(GroupEnd)
     SYM(Send) SYM(Recv) SYM(AllGather) SYM(AllReduce) SYM(GetErrorString)
 #undef SYM
+    if (missing) {      // leave R untouched so that the next call reports the same failure instead of calling NULL
+        snprintf(g_cerr, sizeof g_cerr, "librccl lacks %s", missing);
+        srcnn::set_last_error(g_cerr);
+        dlclose(h);
+        return SRCNN_E_COMM;
+    }
+    r.h = h;
+    R = r;
     return 0;
+}
+
+int comm_fail(const char* what)
+{
+    snprintf(g_cerr, sizeof g_cerr, "%s", what);
+    srcnn::set_last_error(g_cerr);
+    return SRCNN_E_COMM;
 }
 
 #define NCCL_TRY(expr)                                                                         \
@@ -85,15 +103,22 @@ int srcnn_comm_unique_id(unsigned char id[SRCNN_COMM_ID_BYTES])
 int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int nranks)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_comm) return SRCNN_E_ARG;
-    if (rank < 0 || nranks <= 0 || rank >= nranks) return SRCNN_E_ARG;
+    if (g_comm) return comm_fail("srcnn_comm_init: communicator already initialised");
+    if (!id || rank < 0 || nranks <= 0 || rank >= nranks) return comm_fail("srcnn_comm_init: bad rank / nranks / id");
     if (int rc = load()) return rc;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    NCCL_TRY(R.CommInitRank(&g_comm, nranks, u, rank));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(R.CommInitRank(&comm, nranks, u, rank));
+    float* token = nullptr;
+    if (hipMalloc((void**)&token, sizeof(float)) != hipSuccess || hipMemset(token, 0, sizeof(float)) != hipSuccess) {
+        (void)hipFree(token);
+        R.CommDestroy(comm);
+        srcnn::set_last_error("srcnn_comm_init: device allocation failed");
+        return SRCNN_E_DEVMEM;
+    }
+    g_comm = comm; g_token = token;
     g_rank = rank; g_nranks = nranks;
-    if (hipMalloc((void**)&g_token, sizeof(float)) != hipSuccess) return SRCNN_E_DEVMEM;
-    hipMemset(g_token, 0, sizeof(float));
     return SRCNN_OK;
 }
 
@@ -105,40 +130,77 @@ int srcnn_comm_destroy(void)
     R.CommDestroy(g_comm);
     g_comm = nullptr;
     hipFree(g_token); g_token = nullptr;
+    g_rank = 0; g_nranks = 1;
+    return SRCNN_OK;
+}
+
+int srcnn_comm_rank(int* rank, int* nranks)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_comm) return comm_fail("no communicator");
+    if (rank) *rank = g_rank;
+    if (nranks) *nranks = g_nranks;
+    return SRCNN_OK;
+}
+
+// counts[r] floats from rank r land at d_recv + sum(counts[0..r)) on the root: bands of unequal height (an
+// output height that the rank count does not divide) assemble into one contiguous frame.
+int srcnn_comm_gatherv_f32(const float* d_send, const size_t* counts, float* d_recv, int root, void* stream)
+{
+    if (!g_comm) return comm_fail("no communicator");
+    if (!counts || root < 0 || root >= g_nranks) return comm_fail("srcnn_comm_gatherv_f32: bad counts / root");
+    if (counts[g_rank] && !d_send) return comm_fail("srcnn_comm_gatherv_f32: d_send == NULL");
+    if (g_rank == root && !d_recv) return comm_fail("srcnn_comm_gatherv_f32: d_recv == NULL on the root");
+    hipStream_t s = (hipStream_t)stream;
+    // every Send/Recv of the group is attempted and GroupEnd always runs, so a failure never leaves the group open
+    ncclResult_t first_bad = ncclSuccess;
+    auto note = [&](ncclResult_t r) { if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r; };
+    note(R.GroupStart());
+    size_t my_off = 0;
+    if (g_rank == root) {
+        size_t off = 0;
+        for (int r = 0; r < g_nranks; ++r) {
+            if (r == root) my_off = off;
+            else if (counts[r]) note(R.Recv(d_recv + off, counts[r], ncclFloat, r, g_comm, s));
+            off += counts[r];
+        }
+    } else if (counts[g_rank]) {
+        note(R.Send(d_send, counts[g_rank], ncclFloat, root, g_comm, s));
+    }
+    note(R.GroupEnd());
+    if (first_bad != ncclSuccess) {
+        snprintf(g_cerr, sizeof g_cerr, "band gather failed: %s", R.GetErrorString(first_bad));
+        srcnn::set_last_error(g_cerr);
+        return SRCNN_E_COMM;
+    }
+    if (g_rank == root && counts[root] && d_recv + my_off != d_send) {
+        if (hipMemcpyAsync(d_recv + my_off, d_send, counts[root] * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            srcnn::set_last_error("band gather: root's own copy failed");
+            return SRCNN_E_HIP;
+        }
+    }
     return SRCNN_OK;
 }
 
 int srcnn_comm_gather_f32(const float* d_send, size_t count, float* d_recv, int root, void* stream)
 {
-    if (!g_comm) return SRCNN_E_COMM;
-    hipStream_t s = (hipStream_t)stream;
-    NCCL_TRY(R.GroupStart());
-    if (g_rank == root) {
-        for (int r = 0; r < g_nranks; ++r) {
-            if (r == root) continue;
-            NCCL_TRY(R.Recv(d_recv + (size_t)r * count, count, ncclFloat, r, g_comm, s));
-        }
-    } else {
-        NCCL_TRY(R.Send(d_send, count, ncclFloat, root, g_comm, s));
-    }
-    NCCL_TRY(R.GroupEnd());
-    if (g_rank == root && d_recv + (size_t)root * count != d_send) {
-        if (hipMemcpyAsync(d_recv + (size_t)root * count, d_send, count * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return SRCNN_E_HIP;
-    }
-    return SRCNN_OK;
+    if (!g_comm) return comm_fail("no communicator");
+    size_t counts[1024];
+    if (g_nranks > 1024) return comm_fail("too many ranks");
+    for (int r = 0; r < g_nranks; ++r) counts[r] = count;
+    return srcnn_comm_gatherv_f32(d_send, counts, d_recv, root, stream);
 }
 
 int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, void* stream)
 {
-    if (!g_comm) return SRCNN_E_COMM;
+    if (!g_comm) return comm_fail("no communicator");
     NCCL_TRY(R.AllGather(d_send, d_recv, count, ncclFloat, g_comm, (hipStream_t)stream));
     return SRCNN_OK;
 }
 
 int srcnn_comm_barrier(void* stream)
 {
-    if (!g_comm) return SRCNN_E_COMM;
+    if (!g_comm) return comm_fail("no communicator");
     NCCL_TRY(R.AllReduce(g_token, g_token, 1, ncclFloat, ncclSum, g_comm, (hipStream_t)stream));
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SRCNN_E_HIP;
     return SRCNN_OK;
