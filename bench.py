@@ -16,12 +16,19 @@ One JSON line on rank 0.  `value` = output megapixels of ALL ranks / max-over-ra
 live inside the timed region with HIP events recorded on the launch stream by the library
 (srcnn_profile_*), and priced with the algorithmic FLOPs per launch.
 `cpu_baseline` = the reference's own OpenMP path (oracle/_ref, compiled from the reference sources) or the
-C restatement (oracle/) timed on this host's cores on a bounded sample of the same kind of frame.
+C restatement (oracle/) timed on this host's cores, SURVEY.md 8(d) protocol: threads = min(physical cores, 64)
+pinned with OMP_PROC_BIND=close OMP_PLACES=cores, best of 3, config #1 (ProcessSRCNN on the butterfly image) and
+config #2 (one 1080p Y frame).  At N=1 the line also carries the rest of SURVEY 8(d): the PCIe-inclusive rate
+(`pcie_inclusive`), the wall time of ProcessSRCNN itself -- the one number the reference's own harness prints
+(src/test.cpp:653-672) -- for 1080p and 4K RGB (`process_srcnn_ms`), both synthetic generators (`generators`),
+and the non-parity tiers with their measured error.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,41 +41,157 @@ MAC_L12 = 64 * 81 + 32 * 64               # 7232 MAC per output pixel in the dom
 MAC_ALL = MAC_L12 + 32 * 25               # 8032
 PEAK_F32_TFLOPS = 157.3                   # MI355X_MICROARCH.md: FP32 matrix == FP32 vector peak
 PEAK_HBM_GBS = 8000.0
+METRIC = "megapixels/sec SRCNN Y-channel (2x upscale)"
 
 
-def cpu_baseline(S, budget_s=20.0):
-    """The CPU-baseline leg (the only place bench.py touches oracle/): time the reference CPU path on this
-    host -- a calibration frame first, then the largest frame that fits the budget -- and, on that same
-    frame, compare the GPU output with the CPU reference's (the "max |dY| vs CPU ref" half of the metric).
-    Returns (cpu_baseline object, max_abs_dY)."""
-    import oracle
+def physical_cores():
+    """Distinct (package, core) pairs of this host; falls back to the logical count."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+_CPU_CHILD = r"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+from libsrcnn_amd import synth
+budget, outdir = float(sys.argv[2]), sys.argv[3]
+eng, kind = (oracle.Reference(), "reference") if oracle.have_reference() else (oracle.Oracle(), "port")
+res = {"kind": kind}
+t_all = time.perf_counter()
+# config #1: ProcessSRCNN on the butterfly image (256x256x3 -> 512x512x3), best of 3
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "butterfly.npz"))
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); rgb, conv = eng.process(g["rgb_in"], 2.0); ts.append(time.perf_counter() - t0)
+res["config1_butterfly_processsrcnn_s"] = ts
+res["config1_ok"] = bool(np.array_equal(rgb, g["rgb_out"]) and np.array_equal(conv, g["conv_y"]))
+# config #2: one 1920x1080 Y frame -> 3840x2160 (falls back to a quarter frame if one run would blow the budget)
+y = synth.plane(270, 480, synth.SEED0, "smooth")
+t0 = time.perf_counter(); eng.y_path(y); probe = time.perf_counter() - t0
+h, w = (1080, 1920) if probe * 16 * 3 <= budget else (540, 960)
+y = synth.plane(h, w, synth.SEED0, "smooth")
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); out = eng.y_path(y); ts.append(time.perf_counter() - t0)
+    if time.perf_counter() - t_all > budget:
+        break
+np.save(os.path.join(outdir, "cpu_out.npy"), out)
+res.update({"config2_shape": [h, w], "config2_y_path_s": ts})
+print(json.dumps(res))
+"""
+
+
+def cpu_baseline(S, budget_s=30.0):
+    """The CPU-baseline leg (the only place bench.py touches oracle/): the reference CPU path in a child process
+    whose OpenMP runtime is pinned as SURVEY 8(d) asks, then, on that same frame, the GPU output is compared with
+    the CPU reference's (the "max |dY| vs CPU ref" half of the metric).  Returns (cpu_baseline object, max_abs_dY)."""
     from libsrcnn_amd import synth
-    threads = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    if oracle.have_reference():
-        eng, kind = oracle.Reference(), "reference"
-    else:
-        eng, kind = oracle.Oracle(), "port"
-    cases = [(270, 480), (540, 960), (1080, 1920), (2160, 3840)]
-    best = None
-    spent = 0.0
-    for h, w in cases:
-        y = synth.plane(h, w, synth.SEED0, "smooth")
-        t0 = time.perf_counter()
-        ref_out = eng.y_path(y)
-        dt = time.perf_counter() - t0
-        spent += dt
-        best = (h, w, dt, y, ref_out)
-        if spent + dt * 4.2 > budget_s:      # the next size is 4x the pixels
-            break
-    h, w, dt, y, ref_out = best
+    cores = physical_cores()
+    threads = min(cores, 64)          # layer 1 has 64 parallel iterations, layer 2 has 32 (src/libsrcnn.cpp:791,817)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([sys.executable, "-c", _CPU_CHILD, ROOT, str(budget_s), td], env=env, capture_output=True,
+                           text=True, timeout=budget_s * 4 + 60)
+        if r.returncode != 0:
+            raise RuntimeError("cpu baseline child failed: " + r.stderr[-400:])
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        ref_out = np.load(os.path.join(td, "cpu_out.npy"))
+    h, w = res["config2_shape"]
+    best2 = min(res["config2_y_path_s"])
+    best1 = min(res["config1_butterfly_processsrcnn_s"])
+    y = synth.plane(h, w, synth.SEED0, "smooth")
     gpu_out = S.y_upscale2x(y)
     max_abs = float(np.max(np.abs(gpu_out.astype(np.float64) - ref_out.astype(np.float64))))
-    obj = {"value": round(4 * h * w / 1e6 / dt, 4), "unit": "MPix/s", "cores": threads, "kind": kind,
-           "sample": "1 synthetic %dx%d -> %dx%d Y frame, %.2f s wall, OMP_NUM_THREADS=%s (layer 1 can use at most 64 "
-                     "threads, layer 2 at most 32: src/libsrcnn.cpp:791,817); GPU output of the same frame compared "
-                     "element-wise" % (w, h, 2 * w, 2 * h, dt, os.environ["OMP_NUM_THREADS"])}
+    obj = {"value": round(4 * h * w / 1e6 / best2, 4), "unit": "MPix/s", "cores": threads, "kind": res["kind"],
+           "sample": "config #2: one synthetic %dx%d -> %dx%d Y frame, best of %d runs %.2f s; OMP_NUM_THREADS=%d = "
+                     "min(physical cores %d, 64), OMP_PROC_BIND=close OMP_PLACES=cores (layer 1 has 64 parallel "
+                     "iterations, layer 2 has 32: src/libsrcnn.cpp:791,817); GPU output of the same frame compared "
+                     "element-wise" % (w, h, 2 * w, 2 * h, len(res["config2_y_path_s"]), best2, threads, cores),
+           "physical_cores": cores, "logical_cpus": os.cpu_count(),
+           "config2_runs_s": [round(t, 3) for t in res["config2_y_path_s"]],
+           "config1_butterfly_processsrcnn_ms": round(best1 * 1e3, 1),
+           "config1_runs_ms": [round(t * 1e3, 1) for t in res["config1_butterfly_processsrcnn_s"]],
+           "config1_matches_reference_pngs": res["config1_ok"]}
     return obj, max_abs
+
+
+def synth_rgb(h, w, seed):
+    from libsrcnn_amd import synth
+    base = synth.plane(h, w, seed, "smooth")
+    rng = np.random.default_rng(seed & 0xFFFF)
+    img = np.empty((h, w, 3), np.uint8)
+    for k in range(3):
+        img[..., k] = np.clip(base * (0.6 + 0.2 * k) + rng.integers(0, 24, base.shape), 0, 255).astype(np.uint8)
+    return img
+
+
+def process_srcnn_wall(S):
+    """Wall time of ProcessSRCNN(rgb, x2) -- host u8 in, new[]-allocated host u8 out, as a libsrcnn user calls it
+    (and as the reference's harness times it, src/test.cpp:653-672).  Best of 5 after one warm-up."""
+    import ctypes as C
+    L = S.lib()
+    S.ConfigureFilterSRCNN(S.SRCNNF_Bicubic, False)
+    fn = getattr(L, S.CXX_SYMBOLS[1])
+    out = {}
+    for name, (h, w) in (("1920x1080_rgb", (1080, 1920)), ("3840x2160_rgb", (2160, 3840))):
+        img = synth_rgb(h, w, 0x5C0DE000 + h)
+        ts = []
+        for it in range(6):
+            o, osz = C.c_void_p(), C.c_uint(0)
+            t0 = time.perf_counter()
+            rc = fn(img.ctypes.data, w, h, 3, 2.0, C.byref(o), C.byref(osz), None, None)
+            dt = time.perf_counter() - t0
+            assert rc == 0 and osz.value == 4 * h * w * 3, (rc, osz.value)
+            L.srcnn_delete_array(o)
+            if it:
+                ts.append(dt)
+        out[name] = {"best_ms": round(min(ts) * 1e3, 2), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 2),
+                     "MPix/s": round(4 * h * w / 1e6 / min(ts), 1)}
+    out["note"] = "host u8 RGB in -> host u8 RGB out through the drop-in symbol; includes H2D, colour split, chroma " \
+                  "resample, Y path, merge, D2H and the new[] of the result"
+    return out
+
+
+def pcie_inclusive(S, frames=8):
+    """Stream of host-resident (page-locked) 4K Y frames: H2D + path + D2H per frame, two slots, hipGraph per slot."""
+    import ctypes as C
+    L = S.lib()
+    w, h, F = IN_W, IN_H, frames
+    pin_in = L.srcnn_host_alloc_pinned(F * w * h * 4)
+    pin_out = L.srcnn_host_alloc_pinned(F * 4 * w * h * 4)
+    fr = np.ctypeslib.as_array(C.cast(pin_in, C.POINTER(C.c_float)), (F, h, w))
+    out = np.ctypeslib.as_array(C.cast(pin_out, C.POINTER(C.c_float)), (F, 2 * h, 2 * w))
+    from libsrcnn_amd import synth
+    two = synth.frames(2, h, w, 0, "smooth")
+    for f in range(F):
+        fr[f] = two[f & 1]
+    S.check(L.srcnn_y_upscale2x_f32_stream(fr.ctypes.data, w, h, F, out.ctypes.data, 1))     # warm-up + capture
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        S.check(L.srcnn_y_upscale2x_f32_stream(fr.ctypes.data, w, h, F, out.ctypes.data, 1))
+        ts.append(time.perf_counter() - t0)
+    L.srcnn_host_free_pinned(pin_in); L.srcnn_host_free_pinned(pin_out)
+    return {"value": round(F * 4 * w * h / 1e6 / min(ts), 1), "unit": "MPix/s", "frames": F, "best_of": 3,
+            "bytes_per_output_px": {"h2d": 1.0, "d2h": 4.0},
+            "note": "planar f32 Y frames in page-locked host memory, H2D + path + D2H overlapped over two slots "
+                    "(srcnn_y_upscale2x_f32_stream, hipGraph per slot); never the headline value"}
 
 
 def side_workload(args):
@@ -86,50 +209,45 @@ def side_workload(args):
     from libsrcnn_amd import synth, multigpu
     S.init(local_rank % max(1, S.device_count()))
     L = S.lib()
+    extra = {}
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    verify = None
     if args.workload == "tiled8k":
-        w, h = 7680, 4320
-        y = synth.plane(h, w, synth.SEED0, "smooth")
+        import hashlib
+        w, h = args.tiled_size
+        y = synth.plane(h, w, synth.SEED0, "smooth")          # every rank can generate the frame (counter-based)
         d_in = S.DeviceBuffer.from_numpy(y)
-        row0, rows = multigpu.band_rows(2 * h, rank, world)
-        maxrows = multigpu.band_rows(2 * h, 0, world)[1]
-        d_band = S.DeviceBuffer(maxrows * 2 * w * 4)
-        d_full = S.DeviceBuffer(world * maxrows * 2 * w * 4) if rank == 0 else S.DeviceBuffer(16)
-        multigpu.init_comm_from_torch_dist(dist, rank, world) if world > 1 else None
-        if world == 1:
-            import ctypes as C
-            ident = (C.c_ubyte * 128)()
-            S.check(L.srcnn_comm_unique_id(ident)); S.check(L.srcnn_comm_init(ident, 0, 1))
+        multigpu.init_comm_from_torch_dist(dist, rank, world)
+        tiled = multigpu.TiledFrameGPU(w, h, rank, world)
 
         def step():
-            S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, w, h, row0, rows, d_band.ptr, None))
-            S.check(L.srcnn_comm_gather_f32(d_band.ptr, maxrows * 2 * w, d_full.ptr, 0, None))
+            tiled.step(d_in)
+
+        def verify():
+            """Once per run: the gathered frame on the root must be the whole-frame result, bit for bit."""
+            if rank != 0:
+                return None
+            got = hashlib.sha256(tiled.result().tobytes()).hexdigest()
+            d_ref = S.DeviceBuffer(4 * w * h * 4)
+            S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, w, h, d_ref.ptr, None))
+            S.sync()
+            want = hashlib.sha256(d_ref.to_numpy(np.float32, (2 * h, 2 * w)).tobytes()).hexdigest()
+            assert got == want, "gathered frame differs from the whole-frame result"
+            return {"gathered_sha256": got, "equals_whole_frame_call": True}
         mpix_step = 4 * w * h / 1e6
-        label = "one 7680x4320 Y frame -> 15360x8640, %d output bands + RCCL gather to rank 0" % world
+        label = "one %dx%d Y frame -> %dx%d, %d output bands + RCCL gatherv to rank 0" % (w, h, 2 * w, 2 * h, world)
     elif args.workload == "host-stream":
-        w, h, F = 3840, 2160, max(args.frames, 4)
-        import ctypes as C
-        F = max(F, 16)
-        # caller-side page-locked frame buffers (what a capture/playout pipeline would hand over)
-        pin_in = L.srcnn_host_alloc_pinned(F * w * h * 4)
-        pin_out = L.srcnn_host_alloc_pinned(F * 4 * w * h * 4)
-        frames = np.ctypeslib.as_array(C.cast(pin_in, C.POINTER(C.c_float)), (F, h, w))
-        out = np.ctypeslib.as_array(C.cast(pin_out, C.POINTER(C.c_float)), (F, 2 * h, 2 * w))
-        two = synth.frames(2, h, w, rank * F, "smooth")
-        for f in range(F):
-            frames[f] = two[f & 1]
-
-        def step():
-            S.check(L.srcnn_y_upscale2x_f32_stream(frames.ctypes.data, w, h, F, out.ctypes.data, 1))
-        mpix_step = world * F * 4 * w * h / 1e6
-        label = "%d host-resident 3840x2160 frames per rank per step, H2D + compute + D2H overlapped, hipGraph per slot" % F
+        r = pcie_inclusive(S, max(args.frames, 8))
+        if rank == 0:
+            print(json.dumps({"metric": METRIC + " incl. PCIe", **r}), flush=True)
+        return
     elif args.workload == "frames-graph":
         import ctypes as C
-        w, h, F = 3840, 2160, args.frames
+        w, h, F = IN_W, IN_H, args.frames
         d_in = S.DeviceBuffer(F * w * h * 4)
         d_out = S.DeviceBuffer(F * 4 * w * h * 4)
         for f in range(F):
@@ -167,17 +285,33 @@ def side_workload(args):
         t = torch.tensor([ms], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t[0])
+    if verify is not None:
+        extra["verify"] = verify()
     if rank == 0:
-        print(json.dumps({"metric": "megapixels/sec SRCNN Y-channel (2x upscale)", "value": round(mpix_step / (ms * 1e-3), 2),
+        print(json.dumps({"metric": METRIC, "value": round(mpix_step / (ms * 1e-3), 2),
                           "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(ms, 4), "higher_is_better": True,
                           "scaling": "strong" if args.workload == "tiled8k" else "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "config": {"workload": label, "mode": "strict"}}), flush=True)
+                          "data": "synthetic", "config": {"workload": label, "mode": "strict"}, **extra}), flush=True)
     barrier()
     if args.workload == "tiled8k":
         L.srcnn_comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def traffic_record():
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc cannot run inside
+    this process), with where it came from, so a stale figure is visible as such."""
+    for name in ("r02_pmc_conv12.json", "pmc_conv12.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                rec = json.load(open(path))
+                return rec.get("hbm_bytes_per_launch"), "profiles/%s (%s)" % (name, rec.get("measured_at", "round 1, commit e142cbb"))
+            except Exception:
+                pass
+    return None, None
 
 
 def main():
@@ -187,9 +321,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4, help="4K frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only (no PCIe / ProcessSRCNN / tier legs)")
+    ap.add_argument("--tiled-size", type=lambda s: tuple(int(v) for v in s.split("x")), default=(7680, 4320),
+                    help="input WxH of the tiled8k workload (default 7680x4320 -> 15360x8640)")
     ap.add_argument("--workload", default="frames", choices=["frames", "frames-graph", "tiled8k", "host-stream", "batch1080p"],
                     help="frames (default, the headline metric): resident 4K frames sharded across ranks; "
-                         "tiled8k: ONE 7680x4320 frame -> 15360x8640, output bands across ranks + RCCL gather; "
+                         "tiled8k: ONE 7680x4320 frame -> 15360x8640, output bands across ranks + RCCL gather (verified "
+                         "against the whole-frame call once per run); "
                          "host-stream: PCIe-inclusive stream of 4K frames from host memory (hipGraph per slot); "
                          "batch1080p: 64 resident 1920x1080 frames per step; "
                          "frames-graph: the headline workload replayed from one captured hipGraph per step")
@@ -229,11 +367,22 @@ def main():
     n_in, n_out = IN_W * IN_H, 4 * IN_W * IN_H
     d_in = S.DeviceBuffer(F * n_in * 4)
     d_out = S.DeviceBuffer(F * n_out * 4)
-    for f in range(F):   # rank r owns frames r*F .. r*F+F-1 of the synthetic stream
-        d_in.upload(synth.plane(IN_H, IN_W, synth.SEED0 + rank * F + f, "smooth"), offset=f * n_in * 4)
+
+    def load(kind):   # rank r owns frames r*F .. r*F+F-1 of the synthetic stream, seed = 0x5C0DE000 + frame index
+        for f in range(F):
+            d_in.upload(synth.plane(IN_H, IN_W, synth.SEED0 + rank * F + f, kind), offset=f * n_in * 4)
+    load("smooth")
 
     def step():
         S.check(L.srcnn_y_upscale2x_f32_batch_dev(d_in.ptr, IN_W, IN_H, F, d_out.ptr, None))
+
+    def timed(k):
+        S.sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        S.sync()
+        return (time.perf_counter() - t0) / k
 
     for _ in range(args.warmup):
         step()
@@ -266,28 +415,22 @@ def main():
         avg12 = c12_ms / max(c12_n, 1)
         flops12 = 2.0 * MAC_L12 * n_out                         # algorithmic FLOPs of one conv12 launch (one frame)
         achieved = flops12 / (avg12 * 1e-3) / 1e12 if avg12 > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_conv12.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_from = traffic_record()
         stage = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
         alg_bytes12 = (4 + 128) * n_out                         # layer-1+2 kernel: fp32 Y in, 32 fp32 planes out
         out = {
-            "metric": "megapixels/sec SRCNN Y-channel (2x upscale)",
+            "metric": METRIC,
             "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "stream of synthetic 3840x2160 Y frames -> 7680x4320 (2x), %d frames/GPU/step, frames "
-                                   "sharded across ranks, strict (bit-exact) mode" % F,
+                                   "sharded across ranks, strict (bit-exact) mode, generator 'smooth'" % F,
                        "frames_per_gpu_per_step": F, "in": [IN_W, IN_H], "out": [2 * IN_W, 2 * IN_H], "mode": "strict",
                        "parallelism": "frames sharded %d-way, no data-path collective" % world},
             "roofline": {"kernel": "k_conv12_mfma (conv 9x9x1->64 + ReLU + conv 1x1x64->32 + ReLU)",
                          "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_from": traffic_from,
                          "frac_of_no_fma_ceiling": round(achieved / (PEAK_F32_TFLOPS / 2), 4),
                          "avg_launch_ms": round(avg12, 4), "launches": int(c12_n),
                          "flops_per_launch": flops12,
@@ -302,25 +445,39 @@ def main():
             "max_abs_dY_vs_cpu_ref": None,
             "device": S.device_name(),
         }
-        if world == 1:
-            # non-parity tiers, same frames, 2 steps each: reported beside the headline, never as `value`
+        if world == 1 and not args.no_extras:
+            # both generators: the headline above is `smooth`; `noise` is the worst case for rounding
+            gens = {"smooth": round(value, 1)}
+            load("noise")
+            step(); S.sync()
+            gens["noise"] = round(F * n_out / 1e6 / timed(3), 1)
+            load("smooth")
+            out["generators"] = {"MPix/s": gens, "note": "same workload, 3 steps, frames from the other generator"}
+            # non-parity tiers, same frames: throughput AND measured error against the strict result of frame 0
+            # (strict == reference bit for bit, so this IS max|dY| vs the reference on a full 4K->8K frame)
+            step(); S.sync()
+            strict0 = d_out.to_numpy(np.float32, (2 * IN_H, 2 * IN_W))
             tiers = {}
             for mode, name in ((S.MODE_FAST, "fast_fp32_fma"), (S.MODE_FAST_F16, "fast_split_fp16_mfma")):
                 S.set_mode(mode)
                 step(); S.sync()
-                t0f = time.perf_counter()
-                for _ in range(2):
-                    step()
-                S.sync()
-                tiers[name] = {"MPix/s": round(F * n_out / 1e6 / ((time.perf_counter() - t0f) / 2), 1),
-                               "max_abs_dY_vs_reference": "~3e-4 (tests/test_gpu_parity.py: <= 1e-3)"}
+                dt = timed(3)
+                got = d_out.to_numpy(np.float32, (2 * IN_H, 2 * IN_W))
+                tiers[name] = {"MPix/s": round(F * n_out / 1e6 / dt, 1),
+                               "max_abs_dY_vs_reference": float(np.max(np.abs(got.astype(np.float64) - strict0)))}
             S.set_mode(S.MODE_STRICT)
             out["non_parity_tiers"] = tiers
+            del strict0
+            try:
+                out["pcie_inclusive"] = pcie_inclusive(S)
+                out["process_srcnn_ms"] = process_srcnn_wall(S)
+            except Exception as e:                                # noqa: BLE001
+                out["extras_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["max_abs_dY_vs_cpu_ref"] = cpu_baseline(S)
-            except Exception as e:
-                out["cpu_baseline"] = {"value": None, "unit": "MPix/s", "cores": os.cpu_count(), "kind": "port",
+            except Exception as e:                                # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "MPix/s", "cores": physical_cores(), "kind": "port",
                                        "sample": "failed: %s" % e}
         print(json.dumps(out), flush=True)
 

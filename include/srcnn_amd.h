@@ -83,6 +83,10 @@ const char* srcnn_last_error(void);
 int         srcnn_set_mode(int mode);              /* SRCNN_MODE_*; returns previous mode or <0 */
 int         srcnn_get_mode(void);
 int         srcnn_device_name(char* buf, size_t cap);
+/* Upper bound, in bytes, on the layer-2 scratch (128 B per output pixel) one pass may hold; larger frames / bands
+ * are produced in horizontal sub-bands with identical results.  Default 16 GiB or env SRCNN_MAX_WORKSPACE_MB.
+ * Returns the previous limit.  Applies to calls that start afterwards. */
+size_t      srcnn_set_workspace_limit(size_t bytes);
 
 /* ---- device memory / stream / event plumbing so callers need no HIP headers ---- */
 void* srcnn_dev_alloc(size_t bytes);               /* NULL on failure */

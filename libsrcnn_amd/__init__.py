@@ -22,7 +22,7 @@ MODE_STRICT, MODE_FAST, MODE_FAST_F16 = 0, 1, 2
 # every symbol include/srcnn_amd.h declares (checked by tests/test_abi.py)
 C_ABI_SYMBOLS = [
     "srcnn_abi_version", "srcnn_device_count", "srcnn_init", "srcnn_shutdown", "srcnn_last_error",
-    "srcnn_set_mode", "srcnn_get_mode", "srcnn_device_name",
+    "srcnn_set_mode", "srcnn_get_mode", "srcnn_device_name", "srcnn_set_workspace_limit",
     "srcnn_dev_alloc", "srcnn_dev_free", "srcnn_host_alloc_pinned", "srcnn_host_free_pinned",
     "srcnn_memcpy_h2d", "srcnn_memcpy_d2h", "srcnn_memset_dev", "srcnn_stream_create", "srcnn_stream_destroy",
     "srcnn_stream_sync", "srcnn_device_sync", "srcnn_event_create", "srcnn_event_destroy", "srcnn_event_record",
@@ -63,6 +63,7 @@ def lib():
             "srcnn_abi_version": (i, []), "srcnn_device_count": (i, []), "srcnn_init": (i, [i]),
             "srcnn_shutdown": (None, []), "srcnn_last_error": (C.c_char_p, []), "srcnn_set_mode": (i, [i]),
             "srcnn_get_mode": (i, []), "srcnn_device_name": (i, [C.c_char_p, sz]),
+            "srcnn_set_workspace_limit": (sz, [sz]),
             "srcnn_dev_alloc": (vp, [sz]), "srcnn_dev_free": (None, [vp]),
             "srcnn_host_alloc_pinned": (vp, [sz]), "srcnn_host_free_pinned": (None, [vp]),
             "srcnn_memcpy_h2d": (i, [vp, vp, sz, vp]), "srcnn_memcpy_d2h": (i, [vp, vp, sz, vp]),

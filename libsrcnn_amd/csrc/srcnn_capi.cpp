@@ -156,6 +156,11 @@ struct Context {
     bool ready = false;
     int device = 0;
     std::atomic<int> mode{SRCNN_MODE_STRICT};
+    std::atomic<size_t> ws_budget{[] {      // bytes of layer-2 scratch one band may take (srcnn_set_workspace_limit)
+        const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
+        const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
+        return std::max<size_t>(mb, 1) << 20;
+    }()};
     int num_cus = 256;
     int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
@@ -456,26 +461,29 @@ int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw,
     return SRCNN_OK;
 }
 
-// One whole frame.  The 32 layer-2 planes are the big scratch (128 B per output pixel).  Frames whose planes would
-// exceed the workspace budget (default 16 GiB, SRCNN_MAX_WORKSPACE_MB) are produced in horizontal bands --
-// bit-identical to the whole frame -- so a 16K x 16K output needs the same scratch as an 8K one.
-int y_path_frame(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* d_out)
+// Output rows [r0,r1).  The 32 layer-2 planes are the big scratch (128 B per output pixel).  A range whose planes
+// would exceed the workspace budget (default 16 GiB, SRCNN_MAX_WORKSPACE_MB) is produced in horizontal bands --
+// bit-identical to the whole range -- so a 16K x 16K output needs the same scratch as an 8K one.
+int y_path_range(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+                 unsigned r0, unsigned r1, float* d_out)
 {
-    static const size_t budget = [] {
-        const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
-        const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
-        return std::max<size_t>(mb, 1) << 20;
-    }();
+    const size_t budget = g.ws_budget.load();
+    if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
     const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
-    if (row_bytes * dh <= budget) return y_path_rows(c, d_in, w, h, dw, dh, filter, 0, dh, d_out);
+    if (row_bytes * ((size_t)(r1 - r0) + 4) <= budget) return y_path_rows(c, d_in, w, h, dw, dh, filter, r0, r1, d_out);
     const size_t fit = budget / row_bytes;
     const unsigned band = (unsigned)std::max<size_t>(16, fit > 4 ? fit - 4 : 1);
-    for (unsigned r0 = 0; r0 < dh; r0 += band) {
-        const unsigned r1 = std::min(dh, r0 + band);
-        int rc = y_path_rows(c, d_in, w, h, dw, dh, filter, r0, r1, d_out + (size_t)r0 * dw);
+    for (unsigned a = r0; a < r1; a += band) {
+        const unsigned b = std::min(r1, a + band);
+        int rc = y_path_rows(c, d_in, w, h, dw, dh, filter, a, b, d_out + (size_t)(a - r0) * dw);
         if (rc) return rc;
     }
     return SRCNN_OK;
+}
+
+int y_path_frame(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* d_out)
+{
+    return y_path_range(c, d_in, w, h, dw, dh, filter, 0, dh, d_out);
 }
 
 int check_y_path_args(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, const float* d_out)
@@ -626,6 +634,11 @@ int srcnn_set_mode(int mode)
 }
 
 int srcnn_get_mode(void) { return g.mode.load(); }
+
+size_t srcnn_set_workspace_limit(size_t bytes)
+{
+    return g.ws_budget.exchange(std::max<size_t>(bytes, 1u << 20));
+}
 
 int srcnn_device_name(char* buf, size_t cap)
 {
@@ -822,7 +835,7 @@ int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h, un
     if (rows == 0) return fail(SRCNN_E_ARG, "rows == 0");
     if ((unsigned long long)row0 + rows > 2ull * h) return fail(SRCNN_E_ARG, "band [%u,+%u) outside the %u output rows", row0, rows, 2 * h);
     StreamCall sc(stream);
-    return y_path_rows(sc.c, d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, row0, row0 + rows, d_out_band);
+    return y_path_range(sc.c, d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, row0, row0 + rows, d_out_band);
 }
 
 // ---- per-kernel timing -------------------------------------------------------------------------

@@ -35,6 +35,16 @@ def band_input_rows(row0, rows, in_h, margin=8):
     return lo, hi
 
 
+def gather_offsets(counts):
+    """Where rank r's counts[r] elements land in the root's contiguous buffer (what srcnn_comm_gatherv_f32 does):
+    the exclusive prefix sums of the per-rank counts."""
+    offs, pos = [], 0
+    for c in counts:
+        offs.append(pos)
+        pos += c
+    return offs
+
+
 def upscale2x_frame_tiled(y, rank, world, compute_band, gather):
     """Rank-local part of the tiled single-frame path.
     compute_band(y, row0, rows) -> (rows, 2w) float32 band;
@@ -49,23 +59,85 @@ def upscale2x_frame_tiled(y, rank, world, compute_band, gather):
     return np.concatenate([p.reshape(-1, 2 * w) for p in parts], axis=0)
 
 
+def plan(world, frames_per_rank=4, in_w=3840, in_h=2160, tiled_w=7680, tiled_h=4320, devices=None):
+    """Dry run of both shardings for `world` ranks: what every rank would own and allocate, checked for
+    consistency WITHOUT touching a device (tools/run_8gpu.sh --dry-run, tests/test_multi_gpu_cpu.py).
+    Returns a dict; raises AssertionError if the partition is not exact."""
+    devices = world if devices is None else devices
+    out_h, out_w = 2 * tiled_h, 2 * tiled_w
+    ranks = []
+    pos = 0
+    for r in range(world):
+        row0, rows = band_rows(out_h, r, world)
+        assert row0 == pos, (r, row0, pos)
+        pos += rows
+        lo, hi = band_input_rows(row0, rows, tiled_h)
+        ca, cb = max(0, row0 - 2), min(out_h, row0 + rows + 2)
+        ua, ub = max(0, ca - 4), min(out_h, cb + 4)
+        ranks.append({
+            "rank": r, "device": r % max(1, devices),
+            "frames": {"first_index": r * frames_per_rank, "count": frames_per_rank,
+                       "seeds": ["0x%08X" % (0x5C0DE000 + r * frames_per_rank + f) for f in range(frames_per_rank)],
+                       "in_bytes": frames_per_rank * in_w * in_h * 4, "out_bytes": frames_per_rank * 4 * in_w * in_h * 4,
+                       "scratch_bytes": 128 * 4 * in_w * in_h + 4 * 4 * in_w * in_h + 4 * in_w * 2 * in_h},
+            "band": {"row0": row0, "rows": rows, "input_rows": [lo, hi], "count_floats": rows * out_w,
+                     "offset_floats": row0 * out_w, "band_bytes": rows * out_w * 4,
+                     "scratch_bytes": 128 * out_w * (cb - ca) + 4 * out_w * (ub - ua) + 4 * tiled_w * (ub - ua)},
+        })
+    assert pos == out_h
+    counts = [rk["band"]["count_floats"] for rk in ranks]
+    assert sum(counts) == out_h * out_w
+    assert [rk["band"]["offset_floats"] for rk in ranks] == [sum(counts[:r]) for r in range(world)]
+    all_seeds = [s for rk in ranks for s in rk["frames"]["seeds"]]
+    assert len(set(all_seeds)) == len(all_seeds)
+    return {"world": world, "devices": devices, "ranks": ranks, "gather_counts": counts,
+            "tiled_frame": {"in": [tiled_w, tiled_h], "out": [out_w, out_h], "root_bytes": out_h * out_w * 4}}
+
+
 # ---------------------------------------------------------------------------------------------------
 # GPU-side pieces (only imported/used where a device exists)
 # ---------------------------------------------------------------------------------------------------
 def init_comm_from_torch_dist(dist, rank, world):
     """Create the RCCL communicator inside libsrcnn_amd.so, shipping the unique id over an already
-    initialised torch.distributed (gloo) group."""
+    initialised torch.distributed (gloo) group (world == 1: no group needed)."""
     import ctypes as C
     import libsrcnn_amd as S
     ident = (C.c_ubyte * 128)()
     if rank == 0:
         S.check(S.lib().srcnn_comm_unique_id(ident))
-    box = [bytes(ident)]
-    dist.broadcast_object_list(box, src=0)
-    ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    if world > 1:
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
     S.check(S.lib().srcnn_comm_init(ident, rank, world))
 
 
 def gpu_compute_band(d_in, w, h, row0, rows, d_band, stream=None):
     import libsrcnn_amd as S
     S.check(S.lib().srcnn_y_upscale2x_f32_band_dev(d_in.ptr, w, h, row0, rows, d_band.ptr, stream))
+
+
+class TiledFrameGPU:
+    """The device side of upscale2x_frame_tiled: this rank's band through srcnn_y_upscale2x_f32_band_dev, then ONE
+    collective -- srcnn_comm_gatherv_f32, peer->root, per-rank counts -- into a contiguous (2h x 2w) frame on the
+    root.  Buffers are allocated once; step() is what bench.py times."""
+
+    def __init__(self, w, h, rank, world, root=0):
+        import ctypes as C
+        import libsrcnn_amd as S
+        self.S, self.w, self.h, self.rank, self.world, self.root = S, w, h, rank, world, root
+        self.row0, self.rows = band_rows(2 * h, rank, world)
+        self.counts = (C.c_size_t * world)(*[band_rows(2 * h, r, world)[1] * 2 * w for r in range(world)])
+        self.d_band = S.DeviceBuffer(max(1, self.rows) * 2 * w * 4)
+        self.d_full = S.DeviceBuffer(4 * w * h * 4) if rank == root else None
+
+    def step(self, d_in, stream=None):
+        S, L = self.S, self.S.lib()
+        if self.rows:
+            S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, self.w, self.h, self.row0, self.rows, self.d_band.ptr, stream))
+        S.check(L.srcnn_comm_gatherv_f32(self.d_band.ptr, self.counts, self.d_full.ptr if self.d_full else None,
+                                         self.root, stream))
+
+    def result(self):
+        """Host copy of the assembled frame (root only)."""
+        return self.d_full.to_numpy(np.float32, (2 * self.h, 2 * self.w))

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_NORTH_STAR = 1e-4     # the stated tolerance
 TOL_STRICT = 0.0          # what strict mode actually delivers
-TOL_FAST = 1e-3           # FMA contraction: measured ~2e-4 max; bound with margin
+TOL_FAST = 5e-4           # non-parity tiers: measured ~3e-4 max (the reference's own fp32 rounding noise is 2.3e-4)
 
 PLANE_CASES = ["noise_24x40", "noise_29x37", "smooth_33x65", "row_1x17", "col_13x1", "tiny_2x3", "one_1x1",
                "noise_70x9", "smooth_7x130", "wild_12x16"]
@@ -113,11 +113,11 @@ def test_resampler_filters_and_ratios(srcnn, golden, filt):
         assert_bit_equal(srcnn.resample(r["in"], dw, dh, fid), r["%s_%s" % (filt, tag)], filt + tag)
 
 
-def test_bands_equal_whole_frame(srcnn):
-    """Tiling one frame into horizontal bands (multi-GPU config) reproduces the whole-frame result
-    bit for bit, including bands that start/end inside the 6-row receptive field of a border."""
+def test_bands_equal_whole_frame(srcnn, oracle_lib):
+    """Tiling one frame into horizontal bands (multi-GPU config) reproduces the ORACLE's whole-frame result bit for
+    bit, including bands that start/end inside the 6-row receptive field of a border."""
     y = synth.plane(45, 70, synth.SEED0 + 77, "noise")
-    whole = srcnn.y_upscale2x(y)
+    whole = oracle_lib.y_path(y)
     for row0, rows in ((0, 90), (0, 11), (11, 23), (34, 1), (35, 55), (88, 2), (3, 5)):
         band = srcnn.y_upscale2x_band(y, row0, rows)
         assert_bit_equal(band, whole[row0:row0 + rows], "band %d+%d" % (row0, rows))

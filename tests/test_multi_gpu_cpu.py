@@ -72,7 +72,12 @@ def _worker(rank, world, port, shape, seed, q):
         dist.gather(send, recv, dst=0)
         if rank != 0:
             return None
-        return [recv[r][:counts[r]].numpy() for r in range(world)]
+        # place the ragged bands the way srcnn_comm_gatherv_f32 does: contiguous, at the prefix sums of the counts
+        offs = multigpu.gather_offsets(counts)
+        full = np.full((sum(counts), w2), np.nan, np.float32)
+        for r in range(world):
+            full[offs[r]:offs[r] + counts[r]] = recv[r][:counts[r]].numpy()
+        return [full[offs[r]:offs[r] + counts[r]] for r in range(world)]
 
     full = multigpu.upscale2x_frame_tiled(y, rank, world, compute_band, gather)
     # frame-sharded batch: each rank does its own frames, then (only for the test) everything is compared on rank 0
@@ -93,13 +98,14 @@ def _worker(rank, world, port, shape, seed, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape", [(45, 40), (31, 26)])
-def test_world2_gloo_tiled_frame_and_sharded_frames(shape):
+@pytest.mark.parametrize("shape,world", [((45, 40), 2), ((31, 26), 2), ((23, 20), 3)])
+def test_gloo_tiled_frame_and_sharded_frames(shape, world):
+    """world 2 (even and odd band heights) and world 3 (46 output rows -> ragged bands of 16, 15, 15)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, shape, 1234, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, 1234, q)) for r in range(world)]
     for p in procs:
         p.start()
     ok_tiled, ok_frames, out_shape = q.get(timeout=240)
@@ -109,3 +115,34 @@ def test_world2_gloo_tiled_frame_and_sharded_frames(shape):
     assert out_shape == (2 * shape[0], 2 * shape[1])
     assert ok_tiled, "bands gathered over gloo differ from the whole-frame result"
     assert ok_frames
+
+
+def test_plan_is_consistent_for_every_world_size():
+    """The dry run behind tools/run_8gpu.sh --dry-run: rank -> device mapping, frame ownership by seed, band
+    partition, gather counts/offsets and buffer sizes for N in {1,2,4,8} (and a ragged N), no device needed."""
+    for world in (1, 2, 3, 4, 7, 8):
+        p = multigpu.plan(world)
+        assert [r["device"] for r in p["ranks"]] == list(range(world))
+        assert p["ranks"][0]["frames"]["seeds"][0] == "0x5C0DE000"
+        assert p["ranks"][-1]["frames"]["seeds"][-1] == "0x%08X" % (0x5C0DE000 + 4 * world - 1)
+        assert sum(p["gather_counts"]) * 4 == p["tiled_frame"]["root_bytes"] == 15360 * 8640 * 4
+        assert multigpu.gather_offsets(p["gather_counts"]) == [r["band"]["offset_floats"] for r in p["ranks"]]
+        for r in p["ranks"]:
+            lo, hi = r["band"]["input_rows"]
+            assert 0 <= lo < hi <= 4320
+            # +-6 output rows of receptive field = +-5 input rows incl. the 4-tap resampler, all inside [lo, hi)
+            assert lo <= max(0, (r["band"]["row0"] - 6) // 2 - 2) and hi >= min(4320, (r["band"]["row0"] + r["band"]["rows"] + 5) // 2 + 3)
+    eight = multigpu.plan(8)
+    assert all(r["band"]["rows"] == 1080 and r["band"]["band_bytes"] == 66355200 for r in eight["ranks"])   # 66.4 MB per GPU
+    # fewer devices than ranks (a 1-GPU box exercising the N>1 plumbing): ranks wrap around
+    assert [r["device"] for r in multigpu.plan(4, devices=1)["ranks"]] == [0, 0, 0, 0]
+
+
+def test_launcher_dry_run_script():
+    import json
+    import subprocess
+    r = subprocess.run([os.path.join(ROOT, "tools", "run_8gpu.sh"), "--dry-run", "2", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(x) for x in r.stdout.strip().splitlines()]
+    assert [x["world"] for x in lines] == [2, 8]
+    assert lines[1]["band_rows"][7] == [7560, 1080] and lines[1]["band_MB"][0] == 66.4

@@ -6,11 +6,12 @@ butterfly_srcnn_convolution.png).  Integer/byte outputs and float planes alike m
 the oracle restates the same operation order and roundings (see its header).
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
-from conftest import assert_bit_equal
+from conftest import ROOT, assert_bit_equal
 
 
 def test_weights_blob(golden, oracle_lib):
@@ -108,3 +109,17 @@ def test_output_range_and_saturation(oracle_lib):
     out = oracle_lib.y_path(y)
     assert out.min() >= 0.0 and out.max() <= 255.0
     assert (out == 0).any() and (out == 255).any()
+
+
+def test_product_weight_table_matches_golden_blob(golden):
+    """The PRODUCT's own weight image (libsrcnn_amd/csrc/srcnn_weights.inc, compiled into libsrcnn_amd.so) holds
+    exactly the bit patterns of tests/golden/weights_f32.bin (= src/convdata.h in the order b1,W1,b2,W2,b3,W3),
+    and so does the oracle's copy -- the two .inc files are byte-identical tables."""
+    import re
+    def parse(path):
+        text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        return np.array([int(t, 16) for t in re.findall(r"0x[0-9a-fA-F]+", text)], dtype=np.uint32)
+    prod = parse(os.path.join(ROOT, "libsrcnn_amd", "csrc", "srcnn_weights.inc"))
+    assert prod.size == 8129
+    assert np.array_equal(prod, golden.weights.view(np.uint32))
+    assert np.array_equal(parse(os.path.join(ROOT, "oracle", "oracle_weights.inc")), prod)

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Multi-GPU runs of the two shardings on ONE node, one process per GPU:
+#   frames  : resident 4K frames sharded across ranks, no data-path collective   (the headline line, weak scaling)
+#   tiled8k : ONE 7680x4320 frame -> 15360x8640, one output band per rank + RCCL gatherv to rank 0, verified
+#             against the whole-frame result once per run                        (strong scaling)
+# Usage: tools/run_8gpu.sh [--dry-run] [N ...]        default N = 1 2 4 8
+#   --dry-run validates, on the CPU and without touching a device, the rank -> device mapping, per-rank frame
+#   ownership (seed = 0x5C0DE000 + frame index), the band partition and the buffer sizes for every N.
+# The launcher is torch.distributed.run (started BEFORE anything touches the GPU: no exec from a HIP process).
+set -euo pipefail
+cd "$(dirname "$0")/.."
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+DRY=0
+if [ "${1:-}" = "--dry-run" ]; then DRY=1; shift; fi
+NS=("$@"); [ ${#NS[@]} -eq 0 ] && NS=(1 2 4 8)
+PORT=${MASTER_PORT:-29531}
+for N in "${NS[@]}"; do
+    if [ $DRY -eq 1 ]; then
+        python3 - "$N" <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+from libsrcnn_amd import multigpu
+n = int(sys.argv[1])
+p = multigpu.plan(n)
+print(json.dumps({"world": n,
+                  "devices": [r["device"] for r in p["ranks"]],
+                  "first_frame_seed": [r["frames"]["seeds"][0] for r in p["ranks"]],
+                  "band_rows": [[r["band"]["row0"], r["band"]["rows"]] for r in p["ranks"]],
+                  "band_MB": [round(r["band"]["band_bytes"] / 1e6, 1) for r in p["ranks"]],
+                  "band_scratch_GB": [round(r["band"]["scratch_bytes"] / 1e9, 2) for r in p["ranks"]],
+                  "frames_scratch_GB": round(p["ranks"][0]["frames"]["scratch_bytes"] / 1e9, 2),
+                  "root_frame_MB": round(p["tiled_frame"]["root_bytes"] / 1e6, 1)}))
+PY
+        continue
+    fi
+    for WL in frames tiled8k; do
+        echo "== N=$N workload=$WL" >&2
+        if [ "$N" -eq 1 ]; then
+            python3 bench.py --gpus 1 --steps 5 --warmup 2 --workload $WL --no-extras --no-cpu-baseline
+        else
+            python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 \
+                --master-port "$PORT" bench.py --gpus "$N" --steps 5 --warmup 2 --workload $WL
+        fi
+    done
+done
