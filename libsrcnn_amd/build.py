@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrcnn_amd.so")
 
-SOURCES = ["srcnn_kernels.hip", "srcnn_capi.cpp", "srcnn_comm.cpp", "dropin.cpp"]
+SOURCES = ["srcnn_kernels.hip", "srcnn_fused_f16.hip", "srcnn_capi.cpp", "srcnn_comm.cpp", "dropin.cpp"]
 DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "resample_table.hpp", "srcnn_weights.inc",
                   "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h"]
 

@@ -164,6 +164,8 @@ struct Context {
     int num_cus = 256;
     int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
+    FusedF16Weights* fused_w = nullptr;   // device copy of the fused fp16 kernel's weight image
+    bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
     std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
     unsigned long long table_clock = 0;
     std::map<hipStream_t, std::unique_ptr<Workspace>> ws;
@@ -201,6 +203,50 @@ void build_dev_weights(DevWeights& d)
     d.b3 = *b3;
 }
 
+// fp32 -> (hi, lo) fp16 bit patterns of v * 2^8, the same split the device uses for activations
+void split_f16_bits(float v, unsigned short& hi, unsigned short& lo)
+{
+    const _Float16 h = (_Float16)(v * 256.f);
+    const _Float16 l = (_Float16)(v * 256.f - (float)h);
+    memcpy(&hi, &h, 2);
+    memcpy(&lo, &l, 2);
+}
+
+void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
+{
+    memset(&f, 0, sizeof f);
+    for (int s = 0; s < 9; ++s)
+        for (int blk = 0; blk < 2; ++blk)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = 32 * blk + (l & 31), h = l >> 5;
+                    float w = 0.f;
+                    if (h == 0) w = d.w1t[s * 9 + j][ch];
+                    else if (j == 7) w = d.w1t[s * 9 + 8][ch];
+                    split_f16_bits(w, f.w1[s][blk][0][l][j], f.w1[s][blk][1][l][j]);
+                }
+    for (int blk = 0; blk < 2; ++blk)
+        for (int ks = 0; ks < 2; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = l & 31, h = l >> 5;
+                    const int c = 32 * blk + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+                    split_f16_bits(d.w2[m][c], f.w2[blk][ks][0][l][j], f.w2[blk][ks][1][l][j]);
+                }
+    for (int ks = 0; ks < 2; ++ks)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int t = l & 31, h = l >> 5;
+                const int m = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+                split_f16_bits(t < 25 ? d.w3[m][t] : 0.f, f.w3[ks][0][l][j], f.w3[ks][1][l][j]);
+            }
+    for (int hf = 0; hf < 2; ++hf) {
+        for (int r = 0; r < 32; ++r) f.b1[hf * 32 + r] = d.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
+        for (int r = 0; r < 16; ++r) f.b2[hf * 16 + r] = d.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
+    }
+    f.b3 = d.b3;
+}
+
 int ensure_init_locked(int device)
 {
     if (g.ready) {
@@ -225,6 +271,15 @@ int ensure_init_locked(int device)
     HIP_TRY(upload_weights(*dw));
     HIP_TRY(conv12_mfma_prepare());
     HIP_TRY(conv12_f16_prepare());
+    {
+        auto fw = std::make_unique<FusedF16Weights>();
+        build_fused_f16_weights(*dw, *fw);
+        if (!g.fused_w) HIP_TRY(hipMalloc((void**)&g.fused_w, sizeof(FusedF16Weights)));
+        HIP_TRY(hipMemcpy(g.fused_w, fw.get(), sizeof(FusedF16Weights), hipMemcpyHostToDevice));
+        HIP_TRY(fused_f16_prepare());
+        const char* uf = getenv("SRCNN_F16_UNFUSED");
+        g.f16_unfused = uf && atoi(uf) != 0;
+    }
     g.num_cus = prop.multiProcessorCount;
     const char* sel = getenv("SRCNN_CONV12");
     g.conv12_valu = sel && strcmp(sel, "valu") == 0;
@@ -442,6 +497,21 @@ int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw,
     const unsigned ua = ca >= 4 ? ca - 4 : 0, ub = std::min(dh, cb + 4);
     int rc;
     if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
+    const bool fused = c.mode == SRCNN_MODE_FAST_F16 && !g.f16_unfused;
+    if (fused) {
+        // non-parity tier: one kernel for all three layers, no layer-2 planes at all
+        {
+            StageTimer t(SRCNN_STAGE_RESAMPLE, c);
+            if ((rc = resample_rows_range(c, d_in, w, h, dw, dh, filter, ua, ub, ws.up))) return rc;
+        }
+        {
+            StageTimer t(SRCNN_STAGE_CONV12, c);
+            launch_fused_f16(ws.up, (int)dw, (int)dh, (int)ua, (int)(ub - ua), d_out, (int)r0, (int)(r1 - r0), g.fused_w,
+                             g.num_cus, c.s);
+        }
+        HIP_TRY(hipGetLastError());
+        return SRCNN_OK;
+    }
     if ((rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
     {
         StageTimer t(SRCNN_STAGE_RESAMPLE, c);
@@ -470,7 +540,8 @@ int y_path_range(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw
     const size_t budget = g.ws_budget.load();
     if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
     const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
-    if (row_bytes * ((size_t)(r1 - r0) + 4) <= budget) return y_path_rows(c, d_in, w, h, dw, dh, filter, r0, r1, d_out);
+    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !g.f16_unfused;      // the fused kernel has no layer-2 planes
+    if (no_planes || row_bytes * ((size_t)(r1 - r0) + 4) <= budget) return y_path_rows(c, d_in, w, h, dw, dh, filter, r0, r1, d_out);
     const size_t fit = budget / row_bytes;
     const unsigned band = (unsigned)std::max<size_t>(16, fit > 4 ? fit - 4 : 1);
     for (unsigned a = r0; a < r1; a += band) {

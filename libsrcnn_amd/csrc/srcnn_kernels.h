@@ -30,7 +30,29 @@ struct DevAxisTable {          // device pointers into one uploaded AxisTable
     int max_taps;
 };
 
+// Weight image of the fused fp16 kernel (srcnn_fused_f16.hip): every fp32 weight, pre-scaled by 2^8, split into
+// fp16 hi + lo and laid out in MFMA A-fragment order (lane-major, 8 halves per lane per fragment), built once on the
+// host.  The struct is byte-for-byte what the kernel copies into LDS.
+//   w1[s][blk][hl][lane][j]  k-step s = window row; lanes 0-31: taps dx=j, lanes 32-63: only j=7 (dx=8) non-zero;
+//                            row (lane%32) = channel 32*blk + lane%32
+//   w2[blk][ks][hl][lane][j] row = output m = lane%32, k = input channel 32*blk + 16*ks + 8*(j/4) + 4*(lane/32) + j%4
+//   w3[ks][hl][lane][j]      row = tap t = lane%32 (dy*5+dx, rows >= 25 zero), k = channel m = 16*ks + 8*(j/4) + 4*(lane/32) + j%4
+//   b1[half][reg], b2[half][reg]  biases in accumulator-register order
+constexpr int FU_NW = 8;      // waves per workgroup of the fused kernel
+struct FusedF16Weights {
+    unsigned short w1[9][2][2][64][8];
+    unsigned short w2[2][2][2][64][8];
+    unsigned short w3[2][2][64][8];
+    float b1[64];
+    float b2[32];
+    float b3;
+    float pad_[3];
+};
+
 hipError_t upload_weights(const DevWeights& w);
+hipError_t fused_f16_prepare();
+void launch_fused_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* out, int out_row0, int out_rows,
+                      const FusedF16Weights* d_blob, int num_cus, hipStream_t s);
 
 void launch_resample_cols(const float* src, int w, int src_row_base, float* dst, int dst_row0, int dst_rows,
                           const DevAxisTable& t, hipStream_t s);

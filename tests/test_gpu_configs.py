@@ -194,7 +194,12 @@ def test_bands_equal_oracle_crops(srcnn, oracle_lib):
 # ------------------------------------------------------------------------------------------------
 # fast tiers: tighter bound, full-size windows
 # ------------------------------------------------------------------------------------------------
+# Measured against the reference on whole 1080p / 4K frames of both generators (tools/fast_error.py, bench.py):
+# fp32-FMA tier <= 2.8e-4, split-fp16 tier <= 4.3e-4.  The reference itself is 2.3e-4 away from exact arithmetic
+# (SURVEY.md 7), so no evaluation that differs from its rounding order can be pinned much closer than this.
 TOL_FAST = 5e-4
+TOL_FAST_F16 = 6e-4
+TOL = {"MODE_FAST": TOL_FAST, "MODE_FAST_F16": TOL_FAST_F16}
 
 
 @pytest.mark.parametrize("mode_name", ["MODE_FAST", "MODE_FAST_F16"])
@@ -213,8 +218,45 @@ def test_fast_tiers_1080p_border_and_interior(srcnn, oracle_lib, mode_name):
             want = oracle_window(oracle_lib, y, oy, ox, wh, ww)
             err = float(np.max(np.abs(got[oy:oy + wh, ox:ox + ww].astype(np.float64) - want)))
             worst = max(worst, err)
-            assert err <= TOL_FAST, (mode_name, kind, (oy, ox), err)
+            assert err <= TOL[mode_name], (mode_name, kind, (oy, ox), err)
     assert worst > 0.0
+
+
+def test_fused_f16_bands_tiles_and_chunks(srcnn, oracle_lib):
+    """The fused split-fp16 kernel (one launch for all three layers): frames whose width/height straddle its 60-column
+    wave strips, 480-column workgroup strips and row chunks; horizontal bands; and run-to-run determinism."""
+    S = srcnn
+    prev = S.set_mode(S.MODE_FAST_F16)
+    try:
+        for h, w, kind in ((37, 29, "noise"), (40, 31, "smooth"), (100, 245, "noise"), (130, 270, "smooth"), (9, 500, "noise")):
+            y = synth.plane(h, w, synth.SEED0 + 7 * h + w, kind)
+            want = oracle_lib.y_path(y).astype(np.float64)
+            got = S.y_upscale2x(y)
+            assert float(np.max(np.abs(got - want))) <= TOL_FAST_F16, (h, w)
+            assert np.array_equal(got.view(np.uint32), S.y_upscale2x(y).view(np.uint32)), "non-deterministic"
+            for row0, rows in ((0, 1), (2 * h - 1, 1), (3, 7), (2 * h - 9, 9), (0, 2 * h)):
+                band = S.y_upscale2x_band(y, row0, rows)
+                # a band is the same arithmetic on the same values, whatever chunk it falls into
+                assert np.array_equal(band.view(np.uint32), got[row0:row0 + rows].view(np.uint32)), (h, w, row0, rows)
+    finally:
+        S.set_mode(prev)
+
+
+def test_unfused_f16_path_still_available(oracle_lib, tmp_path):
+    """SRCNN_F16_UNFUSED=1 selects the two-kernel form of the tier (k_conv12_f16 + k_conv3_fast) for A/B runs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, libsrcnn_amd as S, oracle;"
+            "from libsrcnn_amd import synth; S.init(0); S.set_mode(S.MODE_FAST_F16);"
+            "y = synth.plane(70, 150, 11, 'noise');"
+            "e = float(np.max(np.abs(S.y_upscale2x(y).astype(np.float64) - oracle.Oracle().y_path(y)))); print('ERR', e)") % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_F16_UNFUSED="1"), capture_output=True, text=True,
+                       timeout=300)
+    assert "ERR" in r.stdout, r.stdout + r.stderr
+    err = float(r.stdout.split("ERR")[1])
+    assert 0.0 < err <= TOL_FAST_F16, err
 
 
 # ------------------------------------------------------------------------------------------------
@@ -448,7 +490,7 @@ def test_canaries_around_device_outputs(srcnn, oracle_lib, shape):
         finally:
             S.set_mode(prev)
         assert gf.intact(), "mode %d wrote outside its output" % mode
-        assert float(np.max(np.abs(gf.data(np.float32, (2 * h, 2 * w)).astype(np.float64) - want))) <= TOL_FAST
+        assert float(np.max(np.abs(gf.data(np.float32, (2 * h, 2 * w)).astype(np.float64) - want))) <= TOL_FAST_F16
 
 
 @pytest.mark.parametrize("shape,d,mul", [((1, 1), 3, 2.0), ((1, 17), 4, 2.0), ((13, 1), 3, 2.0), ((67, 131), 4, 2.0),
