@@ -18,7 +18,9 @@ all: $(LIBDIR)/libsrcnn_amd.so $(BINDIR)/srcnntest
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_$*) -x hip -c $< -o $@
+# the fused kernel is issue-bound beside its MFMAs, where packed fp32 VALU ops are an anti-lever: no SLP packing there
+EXTRA_srcnn_fused_f16 := -fno-slp-vectorize
 
 $(LIBDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(LIBDIR)

@@ -207,6 +207,10 @@ void srcnn_delete_array(unsigned char* p);
  * (weights row stride = window+1 doubles). */
 int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, int* right, double* weights);
 
+/* Diagnostic: the fused non-parity kernel alone on an already upscaled plane (w x h), optionally with in-kernel
+ * s_memtime stamps of workgroup 0 (d_dbg: 8 x 64 x 4 uint64, or NULL).  Used by tools/fused_timeline.py. */
+int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, unsigned long long* d_dbg, void* stream);
+
 /* Test hook: number of contribution tables currently cached (bounded, only unreferenced tables are evicted) and
  * of ProcessSRCNN lanes created so far (at most 4). */
 int srcnn_debug_counts(int* tables, int* lanes);

@@ -36,7 +36,7 @@ C_ABI_SYMBOLS = [
     "srcnn_process_u8",
     "srcnn_delete_array", "srcnn_output_size", "srcnn_axis_table",
     "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_rank", "srcnn_comm_gather_f32",
-    "srcnn_comm_gatherv_f32", "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_debug_counts",
+    "srcnn_comm_gatherv_f32", "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_debug_counts", "srcnn_fused_diag",
 ]
 CXX_SYMBOLS = ["_Z20ConfigureFilterSRCNN15SRCNNFilterTypeb", "_Z12ProcessSRCNNPKhjjjfRPhRjPS1_Pj"]
 
@@ -95,6 +95,7 @@ def lib():
             "srcnn_comm_gatherv_f32": (i, [vp, C.POINTER(sz), vp, i, vp]),
             "srcnn_comm_rank": (i, [C.POINTER(i), C.POINTER(i)]),
             "srcnn_debug_counts": (i, [C.POINTER(i), C.POINTER(i)]),
+            "srcnn_fused_diag": (i, [vp, u, u, vp, vp, vp]),
             "srcnn_comm_barrier": (i, [vp]),
         }
         for name, (res, args) in sig.items():

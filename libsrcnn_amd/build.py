@@ -22,6 +22,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
          "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-value", "-Wno-ignored-attributes", "-D__HIP_PLATFORM_AMD__"]
 
 
+# per-source extras.  The fused kernel is issue-bound beside its MFMAs, where packed fp32 VALU ops are slower than the
+# scalar pair they replace (MI355X_MICROARCH.md, cycle constants): keep the SLP vectoriser from forming them.
+EXTRA_FLAGS = {"srcnn_fused_f16.hip": ["-fno-slp-vectorize"]}
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -43,7 +48,7 @@ def build(force=False, verbose=True):
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

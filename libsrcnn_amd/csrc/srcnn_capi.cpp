@@ -165,6 +165,7 @@ struct Context {
     int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
     FusedF16Weights* fused_w = nullptr;   // device copy of the fused fp16 kernel's weight image
+    int fused_skew = 0;         // SRCNN_FUSED_SKEW: phase offset between SIMD partner waves, in units of 128 cycles
     bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
     std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
     unsigned long long table_clock = 0;
@@ -279,6 +280,8 @@ int ensure_init_locked(int device)
         HIP_TRY(fused_f16_prepare());
         const char* uf = getenv("SRCNN_F16_UNFUSED");
         g.f16_unfused = uf && atoi(uf) != 0;
+        const char* sk = getenv("SRCNN_FUSED_SKEW");
+        if (sk) g.fused_skew = std::max(-1, std::min(200, atoi(sk)));
     }
     g.num_cus = prop.multiProcessorCount;
     const char* sel = getenv("SRCNN_CONV12");
@@ -507,7 +510,7 @@ int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw,
         {
             StageTimer t(SRCNN_STAGE_CONV12, c);
             launch_fused_f16(ws.up, (int)dw, (int)dh, (int)ua, (int)(ub - ua), d_out, (int)r0, (int)(r1 - r0), g.fused_w,
-                             g.num_cus, c.s);
+                             g.num_cus, g.fused_skew, c.s);
         }
         HIP_TRY(hipGetLastError());
         return SRCNN_OK;
@@ -1216,6 +1219,17 @@ int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, 
     if (right) memcpy(right, t.last.data(), sizeof(int) * dst_len);
     if (weights) memcpy(weights, t.weight.data(), sizeof(double) * t.weight.size());
     return t.window;
+}
+
+// Diagnostic (tools/fused_timeline.py): the fused fp16 kernel on a device-resident UPSCALED plane with s_memtime stamps
+// of workgroup 0 written to d_dbg (8 waves x 64 rows x 4 stamps: row start, layer 1 done, layers 2+3 done, row done).
+int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, unsigned long long* d_dbg, void* stream)
+{
+    int rc = ensure_init(); if (rc) return rc;
+    if ((rc = check_plane(d_up, w, h, d_out))) return rc;
+    launch_fused_f16(d_up, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, g.fused_w, g.num_cus, g.fused_skew, (hipStream_t)stream, d_dbg);
+    HIP_TRY(hipGetLastError());
+    return SRCNN_OK;
 }
 
 // test hook: number of cached contribution tables / of ProcessSRCNN lanes created so far

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "../../include/srcnn_amd.h"
 
@@ -44,9 +45,26 @@ thread_local char g_cerr[256];
 int load()
 {
     if (R.h) return 0;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // RCCL must sit on the SAME HIP runtime this library is bound to.  A process that also imports PyTorch has two
+    // ROCm stacks on disk (the wheel bundles its own libamdhip64 / librccl); which libamdhip64 this library got depends
+    // on load order (the dynamic loader dedups by SONAME).  An RCCL from the other stack fails at ncclCommInitRank
+    // ("unhandled cuda error", measured: profiles/r02_import_order.txt).  So: find the file hipFree comes from and
+    // take the librccl that lives next to it, by absolute path; only then fall back to the loader's search.
     void* h = nullptr;
-    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipFree), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash);
+            for (const char* leaf : {"/librccl.so.1", "/librccl.so"}) {
+                h = dlopen((dir + leaf).c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
+        }
+    }
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
     if (!h) {
         snprintf(g_cerr, sizeof g_cerr, "dlopen(librccl) failed: %s", dlerror());
         srcnn::set_last_error(g_cerr);

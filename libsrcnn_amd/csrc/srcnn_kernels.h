@@ -52,7 +52,8 @@ struct FusedF16Weights {
 hipError_t upload_weights(const DevWeights& w);
 hipError_t fused_f16_prepare();
 void launch_fused_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* out, int out_row0, int out_rows,
-                      const FusedF16Weights* d_blob, int num_cus, hipStream_t s);
+                      const FusedF16Weights* d_blob, int num_cus, int skew, hipStream_t s,
+                      unsigned long long* dbg = nullptr);
 
 void launch_resample_cols(const float* src, int w, int src_row_base, float* dst, int dst_row0, int dst_rows,
                           const DevAxisTable& t, hipStream_t s);

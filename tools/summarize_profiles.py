@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -27,33 +27,37 @@ def short(name):
         tier = " [strict]"
     elif "<false" in name:
         tier = " [fast tier]"
-    for key in ("k_conv12_f16", "k_conv12_mfma", "k_conv12", "k_conv3_fast", "k_conv3", "k_resample_rows", "k_resample_cols", "k_rgb_split",
+    for key in ("k_fused_f16", "k_conv12_f16", "k_conv12_mfma", "k_conv12", "k_conv3_fast", "k_conv3", "k_resample_rows", "k_resample_cols", "k_rgb_split",
                 "k_ycc_merge"):
         if key in name:
-            return key + (" [fast tier]" if key in ("k_conv12_f16", "k_conv3_fast") else tier)
+            return key + (" [fast tier]" if key in ("k_fused_f16", "k_conv12_f16", "k_conv3_fast") else tier)
     return name[:40]
 
 
 lines = ["# rocprofv3 summary `%s` (MI355X, `python3 bench.py`, strict mode, 3840x2160 -> 7680x4320 frames)\n" % tag]
-stats = one("kt/**/*_kernel_stats.csv")
-if stats:
-    shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
-    lines.append("## kernel-trace --stats (`%s_kernel_stats.csv`)\n" % tag)
+for sub, title in (("kt", "default bench command (strict headline + its extra legs)"), ("kt_f16", "`bench.py --tier fast_f16` (non-parity fused kernel)")):
+    stats = one(sub + "/**/*_kernel_stats.csv")
+    if not stats:
+        continue
+    name = tag + ("_kernel_stats.csv" if sub == "kt" else "_kernel_stats_f16.csv")
+    shutil.copy(stats, os.path.join(dst, name))
+    lines.append("\n## kernel-trace --stats, %s (`%s`)\n" % (title, name))
     lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
     for r in csv.DictReader(open(stats)):
         lines.append("| %s | %s | %.4f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
                                                        float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 pmc = {}
-for which in ("fetch", "write", "sq"):
-    f = one("pmc_%s/**/*_counter_collection.csv" % which)
-    if not f:
-        continue
-    shutil.copy(f, os.path.join(dst, "%s_pmc_%s.csv" % (tag, which)))
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
-    for (k, c), v in agg.items():
-        pmc.setdefault(k, {})[c] = sum(v) / len(v)
+for which in ("fetch", "write", "sq", "sq2"):
+    for tier in ("strict", "fast_f16"):
+        f = one("pmc_%s_%s/**/*_counter_collection.csv" % (which, tier))
+        if not f:
+            continue
+        shutil.copy(f, os.path.join(dst, "%s_pmc_%s_%s.csv" % (tag, which, tier)))
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            pmc.setdefault(k, {})[c] = sum(v) / len(v)
 if pmc:
     lines.append("\n## PMC, one 3840x2160 frame per launch (separate passes; FETCH_SIZE/WRITE_SIZE are in KiB)\n")
     cols = sorted({c for v in pmc.values() for c in v})
@@ -64,15 +68,21 @@ if pmc:
     if k12 and "FETCH_SIZE" in k12 and "WRITE_SIZE" in k12:
         n_out = 7680 * 4320
         fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024
-        rec = {"kernel": "k_conv12_mfma", "tag": tag, "fetch_bytes": fetch, "write_bytes": write,
+        rec = {"kernel": "k_conv12_mfma", "tag": tag, "measured_at": "round 2, tools/collect_profiles.sh " + tag,
+               "fetch_bytes": fetch, "write_bytes": write,
                "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 132 * n_out,
                "note": "FETCH_SIZE/WRITE_SIZE are KiB, separate passes.  The guide's x2 FETCH correction is for 16 B/lane streams; "
                        "our loads are 4 B/lane, calibrated on k_conv3 of the same run: it requests 5.65 GB (4.25 GB of unique "
                        "layer-2 planes x 1.33 halo) and FETCH_SIZE reads 4.73 GB -- a halved counter would imply 9.5 GB, more "
                        "than was requested -- so FETCH_SIZE is taken at face value.  WRITE_SIZE matches 128 B/px exactly."}
-        json.dump(rec, open(os.path.join(dst, "pmc_conv12.json"), "w"), indent=1)
+        json.dump(rec, open(os.path.join(dst, tag + "_pmc_conv12.json"), "w"), indent=1)
         lines.append("\nconv12 HBM traffic per launch = %.3f GB (fetch %.3f + write %.3f) vs algorithmic %.3f GB -> ratio %.3f"
                      % ((fetch + write) / 1e9, fetch / 1e9, write / 1e9, 132 * n_out / 1e9, (fetch + write) / (132 * n_out)))
+    kf = pmc.get("k_fused_f16 [fast tier]")
+    if kf and "FETCH_SIZE" in kf and "WRITE_SIZE" in kf:
+        n_out = 7680 * 4320
+        lines.append("fused fp16 kernel HBM traffic per launch = fetch %.3f GB + write %.3f GB vs algorithmic %.3f GB (4 B in + 4 B out per pixel)"
+                     % (kf["FETCH_SIZE"] * 1024 / 1e9, kf["WRITE_SIZE"] * 1024 / 1e9, 8 * n_out / 1e9))
 b = one("bench.json")
 if b and os.path.getsize(b):
     shutil.copy(b, os.path.join(dst, tag + "_bench.json"))
