@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 
 # per-source extras.  The fused kernel is issue-bound beside its MFMAs, where packed fp32 VALU ops are slower than the
 # scalar pair they replace (MI355X_MICROARCH.md, cycle constants): keep the SLP vectoriser from forming them.
-EXTRA_FLAGS = {"srcnn_fused_f16.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"srcnn_fused_f16.hip": ["-fno-slp-vectorize"] + os.environ.get("SRCNN_FUSED_CFLAGS", "").split()}
 
 
 def hipcc():

@@ -165,7 +165,6 @@ struct Context {
     int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
     FusedF16Weights* fused_w = nullptr;   // device copy of the fused fp16 kernel's weight image
-    int fused_skew = 0;         // SRCNN_FUSED_SKEW: phase offset between SIMD partner waves, in units of 128 cycles
     bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
     std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
     unsigned long long table_clock = 0;
@@ -242,8 +241,8 @@ void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
                 split_f16_bits(t < 25 ? d.w3[m][t] : 0.f, f.w3[ks][0][l][j], f.w3[ks][1][l][j]);
             }
     for (int hf = 0; hf < 2; ++hf) {
-        for (int r = 0; r < 32; ++r) f.b1[hf * 32 + r] = d.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
-        for (int r = 0; r < 16; ++r) f.b2[hf * 16 + r] = d.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
+        for (int r = 0; r < 32; ++r) f.b1[hf * 32 + r] = 256.f * d.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
+        for (int r = 0; r < 16; ++r) f.b2[hf * 16 + r] = 256.f * d.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
     }
     f.b3 = d.b3;
 }
@@ -280,8 +279,6 @@ int ensure_init_locked(int device)
         HIP_TRY(fused_f16_prepare());
         const char* uf = getenv("SRCNN_F16_UNFUSED");
         g.f16_unfused = uf && atoi(uf) != 0;
-        const char* sk = getenv("SRCNN_FUSED_SKEW");
-        if (sk) g.fused_skew = std::max(-1, std::min(200, atoi(sk)));
     }
     g.num_cus = prop.multiProcessorCount;
     const char* sel = getenv("SRCNN_CONV12");
@@ -510,7 +507,7 @@ int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw,
         {
             StageTimer t(SRCNN_STAGE_CONV12, c);
             launch_fused_f16(ws.up, (int)dw, (int)dh, (int)ua, (int)(ub - ua), d_out, (int)r0, (int)(r1 - r0), g.fused_w,
-                             g.num_cus, g.fused_skew, c.s);
+                             g.num_cus, c.s);
         }
         HIP_TRY(hipGetLastError());
         return SRCNN_OK;
@@ -1227,7 +1224,7 @@ int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, un
 {
     int rc = ensure_init(); if (rc) return rc;
     if ((rc = check_plane(d_up, w, h, d_out))) return rc;
-    launch_fused_f16(d_up, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, g.fused_w, g.num_cus, g.fused_skew, (hipStream_t)stream, d_dbg);
+    launch_fused_f16(d_up, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, g.fused_w, g.num_cus, (hipStream_t)stream, d_dbg);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }

@@ -31,11 +31,27 @@
 // no barrier in the main loop, so the two waves that share a SIMD can sit in different phases -- one in the MFMA-only
 // layer-1 phase while the other does the VALU-heavy layer-2/3 hand-offs -- instead of marching in lockstep.
 //
-// LDS (NW = 8): weight fragments 48 KB + Y rings 60 KB + P buffers 50 KB = 158 KB -> one workgroup per CU, two waves
-// per SIMD.  HBM traffic: 4 B in + 4 B out per pixel (+ 6.7 % / chunk-halo re-reads, all L2 hits).
+// LDS (NW = 8): weight fragments + biases 48.4 KB + Y rings 60 KB + P buffers 50 KB = 158.4 KB -> one workgroup per
+// CU, two waves per SIMD.  HBM traffic: 4 B in + 4 B out per pixel (+ 6.7 % / chunk-halo re-reads, all L2 hits).
+//
+// Schedule (measured on MI355X with tools/fused_timeline.py, 7680x4320 frame; profiles/r02_fused_variants.txt):
+//   * Every LDS operand -- layer-1 fragments, W2/W3 fragments, biases -- is requested one 12-MFMA region before its use,
+//     pinned with sched_barrier: left alone the compiler re-loads operands right before they are needed (~70 exposed LDS
+//     latencies per row).  Biases enter as the C operand of the MFMA that opens a chain, not as VALU adds.
+//   * The hi/lo split is 4 instructions per pair of values; only v_fma_mix_f32 is inline asm, both fp16 conversions are
+//     compiler-visible so that every register an MFMA reads was written by an instruction the hazard recogniser sees
+//     (asm feeding an MFMA directly produced wrong results as soon as the scheduler moved the MFMA next to it).
+//   * FU_SEQ=1 (default): per row, layer 1 (108 MFMAs, priority FU_PRIO) then layers 2+3 and the gather (36 MFMAs + all
+//     the VALU work, priority 0).  The raised priority in the MFMA-only phase makes the two waves of a SIMD complement
+//     each other: without it the older wave wins every arbitration (9.5k vs 16.7k cycles per row, the workgroup waits
+//     for the slow half); with it both run ~11.8k cycles per row = 5.9k per row-wave, 78 % of the MFMA floor (4608).
+//   * FU_SEQ=0: the previous row's layers 2+3 cut into nine slices and woven into the next row's layer-1 k-steps
+//     (sched_group_barrier).  Needs both accumulator sets: 256 VGPRs spill at two waves per SIMD; with one wave per
+//     SIMD (FU_NW_DEF=4, 428 registers) it runs 7.6k cycles per row -- slower than two simpler waves.  Kept for A/B.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 #include "srcnn_kernels.h"
 
 #pragma clang fp contract(off)
@@ -60,16 +76,27 @@ constexpr int RING = SLOTS * SB;                 // bytes per wave
 constexpr int PS = 64;                           // P plane stride (floats)
 constexpr int PW = 25 * PS;                      // floats per wave
 constexpr float F_INV = 1.f / 256.f;             // undoes FusedF16Weights' 2^8 weight scale (exact)
+#ifndef FU_WEAVE
+#define FU_WEAVE 1
+#endif
+#ifndef FU_SEQ
+#define FU_SEQ 1
+#endif
+#ifndef FU_PRIO
+#define FU_PRIO 2
+#endif
 
 constexpr int L_W1 = 0;                                          // byte offsets into dynamic LDS
 constexpr int L_W2 = L_W1 + (int)sizeof(FusedF16Weights::w1);
 constexpr int L_W3 = L_W2 + (int)sizeof(FusedF16Weights::w2);
-constexpr int L_Y = L_W3 + (int)sizeof(FusedF16Weights::w3);
+constexpr int L_B1 = L_W3 + (int)sizeof(FusedF16Weights::w3);
+constexpr int L_B2 = L_B1 + 64 * 4;
+constexpr int L_Y = L_B2 + 32 * 4;
 constexpr int L_P = L_Y + NW * RING;
 constexpr int L_END = L_P + NW * PW * 4;
 static_assert(L_Y % 16 == 0 && L_P % 16 == 0, "alignment");
 static_assert(L_END <= 160 * 1024, "LDS budget");
-static_assert(offsetof(FusedF16Weights, b1) == L_Y, "the weight fragments are the head of the blob");
+static_assert(offsetof(FusedF16Weights, b1) == L_B1 && offsetof(FusedF16Weights, b2) == L_B2, "blob head == LDS image");
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -83,23 +110,22 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo)
 
 // 8 accumulator values -> the hi and lo B fragments of one 16-deep k-step.  Two values at a time: pack their fp16 heads
 // (round to nearest), subtract each head from its value with v_fma_mix_f32 reading the fp16 half in place (exact), pack
-// the fp16 tails: 4 instructions per pair.  (Left to the compiler the same arithmetic takes ~7: it unpacks the heads
-// back to fp32 first.)
+// the fp16 tails: 4 instructions per pair.  Only the v_fma_mix_f32 is inline asm (the compiler folds fma(h, -1, x) to a
+// subtraction of the unpacked head, 7 instructions per pair); both conversions are ordinary code, so every register an
+// MFMA reads is written by an instruction the hazard recogniser can see.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float* x, h8& xh, h8& xl)
 {
-    u32x4 hv, lv;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        unsigned hp, lp;
+        const h2 hp = {(_Float16)x[2 * p], (_Float16)x[2 * p + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, hp);
         float r0, r1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(x[2 * p]), "v"(x[2 * p + 1]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(x[2 * p]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(x[2 * p + 1]));
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(r0), "v"(r1));
-        hv[p] = hp; lv[p] = lp;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x[2 * p]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x[2 * p + 1]));
+        xh[2 * p] = hp[0]; xh[2 * p + 1] = hp[1];
+        xl[2 * p] = (_Float16)r0; xl[2 * p + 1] = (_Float16)r1;
     }
-    xh = __builtin_bit_cast(h8, hv);
-    xl = __builtin_bit_cast(h8, lv);
 }
 
 __device__ __forceinline__ h8 as_h8(u32x4 v) { return __builtin_bit_cast(h8, v); }
@@ -114,14 +140,14 @@ template <bool DIAG>
 __global__ __launch_bounds__(NT) void k_fused_f16(
     const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,     // Y holds rows [y_row_base, +y_rows)
     float* __restrict__ out, int out_row0, int out_rows,                        // writes rows [out_row0, +out_rows)
-    const FusedF16Weights* __restrict__ blob, int chunk_rows, int tiles_x, int skew, unsigned long long* __restrict__ dbg)
+    const FusedF16Weights* __restrict__ blob, int chunk_rows, int tiles_x, unsigned long long* __restrict__ dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const _Float16* W1f = reinterpret_cast<const _Float16*>(lds_raw + L_W1);
     const _Float16* W2f = reinterpret_cast<const _Float16*>(lds_raw + L_W2);
     const _Float16* W3f = reinterpret_cast<const _Float16*>(lds_raw + L_W3);
-    const float* B1s = blob->b1;                                // biases: read once, live in registers
-    const float* B2s = blob->b2;
+    const float* B1s = reinterpret_cast<const float*>(lds_raw + L_B1);     // biases stay in LDS: 48 VGPRs are worth more
+    const float* B2s = reinterpret_cast<const float*>(lds_raw + L_B2);
     float* Pall = reinterpret_cast<float*>(lds_raw + L_P);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     const int R1 = min(R0 + chunk_rows, out_row0 + out_rows);
     if (R0 >= R1) return;                                       // uniform per workgroup, before the barrier
 
-    {   // weight fragments: the head of the blob is the LDS image
+    {   // weight fragments + biases: the head of the blob is the LDS image
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(lds_raw);
         for (int e = tid; e < L_Y / 16; e += NT) dst[e] = src[e];
@@ -141,7 +167,8 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
 
     const int cx0 = GX0 + OW * wv - 2;                          // image column of this wave's layer-2 column 0
     const int TX0 = cx0 - 4;                                    // image column of this wave's staged column 0
-    const int ubase = R0 - 6;                                   // virtual Y row held by ring slot 0 (mod 12)
+    const int A0 = clampi(R0 - 2, 0, H - 1);                    // first layer-2 row this chunk computes
+    const int ubase = A0 - 4;                                   // virtual Y row held by ring slot 0 (mod 12)
     const int y_last = y_row_base + y_rows - 1;
     unsigned char* Yr = lds_raw + L_Y + wv * RING;              // this wave's ring: [slot][hi0 | hi1 | lo0 | lo1][80 halves]
 
@@ -180,11 +207,6 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     };
     for (int k = 0; k < SLOTS / STAGE; ++k) { fetch(ubase + STAGE * k); land(ubase + STAGE * k); }
     wave_sync();
-    // Waves w and w + NW/2 share a SIMD.  A one-off offset of about half a row puts them in opposite phases.
-    if (wv >= NW / 2)
-        for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(2);
-    if constexpr (DIAG) { if (skew < 0 && wv >= NW / 2) return; }      // timing experiment: one wave per SIMD (output incomplete)
-
     // ---- per-lane constants ----
     float* Pw = Pall + wv * PW;
     int pidx[5];                                                // P column read for dx = 0..4 (clamped to the image)
@@ -200,133 +222,195 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     asm volatile("" : "+v"(frag_hi));
 
     float O[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                     // partial sums of output rows v+2 .. v-2
-    int a_prev = -0x40000000;
     const int nv = R1 - R0 + 4;                                 // virtual layer-2 rows R0-2 .. R1+1
+    int st_cur = 0;                                             // ring stage: rows A0+4*st_cur .. +3 are computable
+    if (A0 + STAGE <= min(R1 + 1, H - 1)) fetch(ubase + SLOTS);
 
-    for (int st = 0; st * STAGE < nv; ++st) {
-        const bool more = (st + 1) * STAGE < nv;
-        if (more) fetch(ubase + SLOTS + STAGE * st);
-#pragma unroll 1
-        for (int i = 0; i < STAGE; ++i) {
-            const int v = R0 - 2 + STAGE * st + i;
-            if (v > R1 + 1) break;
-            const int a = clampi(v, 0, H - 1);                  // the reference clamps layer-2 ACTIVATIONS at the border
-            unsigned long long t_a = 0, t_b = 0, t_c = 0;
-            if constexpr (DIAG) t_a = __builtin_amdgcn_s_memtime();
-            if (a != a_prev) {
-                a_prev = a;
-                // ================= layer 1: 9 k-steps (one window row each), both segments share the A fragments =====
-                f32x16 acc[2][2] = {};
-                const int s0 = mod12(a - 4 - ubase);               // ring slot of the first window row (uniform)
-                // Software pipeline: the fragments of k-step s+1 are requested from LDS BEFORE the 12 MFMAs of k-step s
-                // are issued, so their latency hides under 384 cycles of matrix work instead of stalling the wave.
-                h8 bh[2], bl[2], a0h, a0l, a1h, a1l;
-                auto load_step = [&](int s, h8 (&xbh)[2], h8 (&xbl)[2], h8& x0h, h8& x0l, h8& x1h, h8& x1l) {
-                    const int slot = s0 + s >= SLOTS ? s0 + s - SLOTS : s0 + s;
-                    const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + slot * SB));
-                    const unsigned* yl = yh + 2 * PB / 4;
+    // ---------------------------------------------------------------------------------------------------------------
+    // One pipeline step = layer 1 of row `a_nxt` (108 MFMAs, nothing else to do) woven together with layers 2+3, the P
+    // hand-over and the gather of the PREVIOUS row (36 MFMAs and all of the VALU work): the previous row's work is cut
+    // into nine slices, one per layer-1 k-step, so every 12-MFMA k-step has ~64 VALU instructions to issue in its
+    // shadow and the matrix pipe never waits for a conversion chain.  Accumulators ping-pong between two sets.
+    // ---------------------------------------------------------------------------------------------------------------
+    f32x16 accA[2][2], accB[2][2];
+    auto step = [&](auto DO_L1, auto DO_L23, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], int a_nxt, int v_prev, int row_idx) {
+        constexpr bool L1 = decltype(DO_L1)::value, L23 = decltype(DO_L23)::value;
+        if constexpr (DIAG) {
+            if (blockIdx.x == 0 && lane == 0 && row_idx < 64 && dbg) dbg[((size_t)wv * 64 + row_idx) * 4] = __builtin_amdgcn_s_memtime();
+        }
+        int s0 = 0;
+        h8 bh[2], bl[2], a0h, a0l, a1h, a1l;
+        auto load_step = [&](int s, h8 (&xbh)[2], h8 (&xbl)[2], h8& x0h, h8& x0l, h8& x1h, h8& x1l) {
+            const int slot = s0 + s >= SLOTS ? s0 + s - SLOTS : s0 + s;
+            const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + slot * SB));
+            const unsigned* yl = yh + 2 * PB / 4;
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        u32x4 hi4, lo4;
+            for (int g = 0; g < 2; ++g) {
+                u32x4 hi4, lo4;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
-                        xbh[g] = as_h8(hi4); xbl[g] = as_h8(lo4);
-                    }
-                    x0h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 0) * 64 + lane) * 8);
-                    x0l = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 1) * 64 + lane) * 8);
-                    x1h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 1) * 2 + 0) * 64 + lane) * 8);
-                    x1l = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 1) * 2 + 1) * 64 + lane) * 8);
-                };
-                load_step(0, bh, bl, a0h, a0l, a1h, a1l);
+                for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
+                xbh[g] = as_h8(hi4); xbl[g] = as_h8(lo4);
+            }
+            x0h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 0) * 64 + lane) * 8);
+            x0l = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 1) * 64 + lane) * 8);
+            x1h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 1) * 2 + 0) * 64 + lane) * 8);
+            x1l = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 1) * 2 + 1) * 64 + lane) * 8);
+        };
+        // The previous row's work comes in "units" of 8 activations x 2 pieces -> 3 MFMAs; slice s of the step runs
+        // the two units U[s][0..1].  kind 2 = layer 2 (W2 fragment blk*2+ks), kind 3 = layer 3 (W3 fragment ks).
+        struct Unit { int kind, g, blk, ks; };
+        constexpr Unit U[9][2] = {{{2, 0, 0, 0}, {2, 0, 0, 1}}, {{2, 0, 1, 0}, {2, 0, 1, 1}}, {{2, 1, 0, 0}, {2, 1, 0, 1}},
+                                  {{2, 1, 1, 0}, {2, 1, 1, 1}}, {{3, 0, 0, 0}, {3, 0, 0, 1}}, {{3, 1, 0, 0}, {3, 1, 0, 1}},
+                                  {{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+        // every LDS operand is requested one region before it is used (the compiler, left alone, re-loads operands right
+        // before their use and the wave then sits out the LDS latency ~70 times per row)
+        auto load_units = [&](int s, h8 (&f)[2][2]) {
+            if constexpr (L23) {
 #pragma unroll
-                for (int s = 0; s < 9; ++s) {
-                    h8 nbh[2], nbl[2], n0h, n0l, n1h, n1l;
-                    if (s + 1 < 9) load_step(s + 1, nbh, nbl, n0h, n0l, n1h, n1l);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh[g], acc[g][0], 0, 0, 0);
-                        acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh[g], acc[g][1], 0, 0, 0);
-                        acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl[g], acc[g][0], 0, 0, 0);
-                        acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl[g], acc[g][1], 0, 0, 0);
-                        acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh[g], acc[g][0], 0, 0, 0);
-                        acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh[g], acc[g][1], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s + 1 < 9) {
-                        bh[0] = nbh[0]; bh[1] = nbh[1]; bl[0] = nbl[0]; bl[1] = nbl[1];
-                        a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+                for (int u = 0; u < 2; ++u) {
+                    const Unit q = U[s][u];
+                    if (q.kind == 2) {
+                        f[u][0] = *reinterpret_cast<const h8*>(W2f + (((q.blk * 2 + q.ks) * 2 + 0) * 64 + lane) * 8);
+                        f[u][1] = *reinterpret_cast<const h8*>(W2f + (((q.blk * 2 + q.ks) * 2 + 1) * 64 + lane) * 8);
+                    } else if (q.kind == 3) {
+                        f[u][0] = *reinterpret_cast<const h8*>(W3f + ((q.ks * 2 + 0) * 64 + lane) * 8);
+                        f[u][1] = *reinterpret_cast<const h8*>(W3f + ((q.ks * 2 + 1) * 64 + lane) * 8);
                     }
                 }
-                if constexpr (DIAG) { asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][15])); t_b = __builtin_amdgcn_s_memtime(); }
-                // ================= layers 2 and 3 per segment: accumulator tiles are the next B operands =============
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    f32x16 acc2 = {};
-#pragma unroll
-                    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            float x[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                x[j] = fmaxf(__builtin_fmaf(acc[g][blk][8 * ks + j], F_INV, B1s[half * 32 + 16 * blk + 8 * ks + j]), 0.f);
-                            h8 xh, xl;
-                            split8(x, xh, xl);
-                            const h8 ah = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 0) * 64 + lane) * 8);
-                            const h8 al = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 1) * 64 + lane) * 8);
-                            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc2, 0, 0, 0);
-                            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc2, 0, 0, 0);
-                            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc2, 0, 0, 0);
-                        }
-                    f32x16 accp = {};
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        float x[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            x[j] = fmaxf(__builtin_fmaf(acc2[8 * ks + j], F_INV, B2s[half * 16 + 8 * ks + j]), 0.f);
-                        h8 xh, xl;
-                        split8(x, xh, xl);
-                        const h8 ah = *reinterpret_cast<const h8*>(W3f + ((ks * 2 + 0) * 64 + lane) * 8);
-                        const h8 al = *reinterpret_cast<const h8*>(W3f + ((ks * 2 + 1) * 64 + lane) * 8);
-                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, accp, 0, 0, 0);
-                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, accp, 0, 0, 0);
-                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, accp, 0, 0, 0);
-                    }
-                    // P rows of this segment: register r of half h is tap 8*(r/4) + 4h + r%4; taps >= 25 are padding
-#pragma unroll
-                    for (int r = 0; r < 13; ++r) {
-                        const int t0 = 8 * (r >> 2) + (r & 3);          // + 4*half
-                        if (r < 12 || half == 0) Pw[(t0 + 4 * half) * PS + 32 * g + col] = accp[r] * F_INV;
-                    }
-                }
+            }
+        };
+        f32x16 c1b[2] = {}, c2b = {};                            // biases (x 2^8), used as the C operand that opens a chain
+        h8 fa[2][2] = {};
+        if constexpr (L1) {
+            if (((a_nxt - A0) >> 2) > st_cur) {                 // the row opens the next ring stage (uniform branch)
+                wave_sync();                                    // this wave no longer reads the slots it overwrites
+                land(ubase + SLOTS + STAGE * st_cur);
+                ++st_cur;
+                if (A0 + STAGE * (st_cur + 1) <= min(R1 + 1, H - 1)) fetch(ubase + SLOTS + STAGE * st_cur);
                 wave_sync();
             }
-            if constexpr (DIAG) t_c = __builtin_amdgcn_s_memtime();
-            // ================= layer-3 gather: layer-2 row v feeds output rows v+2-dy with tap row dy ===================
+            s0 = mod12(a_nxt - 4 - ubase);                      // ring slot of the first window row (uniform)
+            load_step(0, bh, bl, a0h, a0l, a1h, a1l);
+            c1b[0] = *reinterpret_cast<const f32x16*>(B1s + half * 32);
+            c1b[1] = *reinterpret_cast<const f32x16*>(B1s + half * 32 + 16);
+        }
+        if constexpr (L23) c2b = *reinterpret_cast<const f32x16*>(B2s + half * 16);
+        load_units(0, fa);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x16 acc2[2] = {}, accp[2] = {};
+        auto run_unit = [&](Unit q, const h8 (&f)[2]) {
+            float x[8];
+            if (q.kind == 2) {
 #pragma unroll
-            for (int dy = 0; dy < 5; ++dy)
+                for (int j = 0; j < 8; ++j) x[j] = fmaxf(cur[q.g][q.blk][8 * q.ks + j] * F_INV, 0.f);
+            } else {
 #pragma unroll
-                for (int dx = 0; dx < 5; ++dx) O[dy] += Pw[(dy * 5 + dx) * PS + pidx[dx]];
-            const int orow = v - 2;                                 // complete: its last contribution was tap row 4
-            if (orow >= R0 && ox_ok) out[(size_t)(orow - out_row0) * W + ox] = fminf(fmaxf(O[4] + b3, 0.f), 255.f);
-            O[4] = O[3]; O[3] = O[2]; O[2] = O[1]; O[1] = O[0]; O[0] = 0.f;
-            if constexpr (DIAG) {
-                const int idx = STAGE * st + i;
-                if (blockIdx.x == 0 && lane == 0 && idx < 64 && dbg) {
-                    unsigned long long* d = dbg + ((size_t)wv * 64 + idx) * 4;
-                    d[0] = t_a; d[1] = t_b; d[2] = t_c; d[3] = __builtin_amdgcn_s_memtime();
+                for (int j = 0; j < 8; ++j) x[j] = fmaxf(acc2[q.g][8 * q.ks + j] * F_INV, 0.f);
+            }
+            h8 xh, xl;
+            split8(x, xh, xl);
+            f32x16& d = q.kind == 2 ? acc2[q.g] : accp[q.g];
+            const bool opens = q.kind == 2 && q.blk == 0 && q.ks == 0;          // layer-2 chain starts from its bias
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], xh, opens ? c2b : d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], xl, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], xh, d, 0, 0, 0);
+        };
+        auto pw = [&](int g) {                                  // P rows of a segment: register r of half h is tap 8*(r/4)+4h+r%4
+#pragma unroll
+            for (int r = 0; r < 13; ++r) {
+                const int t0 = 8 * (r >> 2) + (r & 3);
+                if (r < 12 || half == 0) Pw[(t0 + 4 * half) * PS + 32 * g + col] = accp[g][r] * F_INV;
+            }
+        };
+        auto slice = [&](int s) {
+            if constexpr (L23) {
+                if (s == 5) pw(0);
+                if (s == 6) pw(1);
+                if (U[s][0].kind) { run_unit(U[s][0], fa[0]); run_unit(U[s][1], fa[1]); }
+                if (s == 7) {
+                    wave_sync();
+                    // layer-3 gather: layer-2 row v feeds output rows v+2-dy with tap row dy
+#pragma unroll
+                    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 5; ++dx) O[dy] += Pw[(dy * 5 + dx) * PS + pidx[dx]];
+                }
+                if (s == 8) {
+                    const int orow = v_prev - 2;                // complete: its last contribution was tap row 4
+                    if (orow >= R0 && ox_ok) out[(size_t)(orow - out_row0) * W + ox] = fminf(fmaxf(O[4] + b3, 0.f), 255.f);
+                    O[4] = O[3]; O[3] = O[2]; O[2] = O[1]; O[1] = O[0]; O[0] = 0.f;
+                    __builtin_amdgcn_wave_barrier();            // the next row overwrites Pw
                 }
             }
-            __builtin_amdgcn_wave_barrier();                        // the next row overwrites Pw
+        };
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            h8 nbh[2], nbl[2], n0h, n0l, n1h, n1l, fn[2][2] = {};
+            if constexpr (L1) { if (s + 1 < 9) load_step(s + 1, nbh, nbl, n0h, n0l, n1h, n1l); }
+            if (s + 1 < 9) load_units(s + 1, fn);
+            __builtin_amdgcn_sched_barrier(0);                  // requests first: they may not sink towards their uses
+            slice(s);
+            if constexpr (L1) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh[g], s == 0 ? c1b[0] : nxt[g][0], 0, 0, 0);
+                    nxt[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh[g], s == 0 ? c1b[1] : nxt[g][1], 0, 0, 0);
+                    nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl[g], nxt[g][0], 0, 0, 0);
+                    nxt[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl[g], nxt[g][1], 0, 0, 0);
+                    nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh[g], nxt[g][0], 0, 0, 0);
+                    nxt[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh[g], nxt[g][1], 0, 0, 0);
+                }
+            }
+            if (L1 && L23 && FU_WEAVE && s < 7) {
+                // weave the region: one MFMA, then up to five VALU in its shadow (an MFMA holds the issue port for 8 of
+                // its 32 cycles; ~5 other instructions fit in the rest)
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // slices stay with their k-step
+            if (s + 1 < 9) {
+                if constexpr (L1) {
+                    bh[0] = nbh[0]; bh[1] = nbh[1]; bl[0] = nbl[0]; bl[1] = nbl[1];
+                    a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
+                }
+                fa[0][0] = fn[0][0]; fa[0][1] = fn[0][1]; fa[1][0] = fn[1][0]; fa[1][1] = fn[1][1];
+            }
         }
-        if (more) {
-            wave_sync();                                        // this wave has finished reading the slots it overwrites
-            land(ubase + SLOTS + STAGE * st);
-            wave_sync();
-        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto row_of = [&](int k) { return clampi(R0 - 2 + k, 0, H - 1); };    // the reference clamps layer-2 ACTIVATIONS at the border
+
+#if FU_SEQ
+    // sequential form (A/B experiment): layer 1 of a row, then its layers 2+3 -- no cross-row overlap, half the accumulators
+#pragma unroll 1
+    for (int k = 0; k < nv; ++k) {
+        // The wave in its MFMA-only phase outranks its SIMD partner, whose VALU-heavy phase then runs in the shadows of
+        // those MFMAs (without this the older wave of the pair simply wins every arbitration: 9.5k vs 16.7k cycles/row)
+        __builtin_amdgcn_s_setprio(FU_PRIO);
+        step(T{}, F{}, accB, accA, row_of(k), 0, k);
+        __builtin_amdgcn_s_setprio(0);
+        step(F{}, T{}, accA, accB, 0, R0 - 2 + k, k);
     }
+#else
+    step(T{}, F{}, accB, accA, row_of(0), 0, 0);                           // prologue: layer 1 of the first row -> accA
+    int k = 1;
+#pragma unroll 1
+    for (; k + 1 < nv; k += 2) {
+        step(T{}, T{}, accA, accB, row_of(k), R0 - 2 + k - 1, k);
+        step(T{}, T{}, accB, accA, row_of(k + 1), R0 - 2 + k, k + 1);
+    }
+    if (k < nv) {
+        step(T{}, T{}, accA, accB, row_of(k), R0 - 2 + k - 1, k);
+        step(F{}, T{}, accB, accA, 0, R0 - 2 + k, k + 1);                  // epilogue
+    } else {
+        step(F{}, T{}, accA, accB, 0, R0 - 2 + k - 1, k);
+    }
+#endif
 }
 
 hipError_t fused_f16_prepare()
@@ -337,7 +421,7 @@ hipError_t fused_f16_prepare()
 }
 
 void launch_fused_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* out, int out_row0, int out_rows,
-                      const FusedF16Weights* d_blob, int num_cus, int skew, hipStream_t s, unsigned long long* dbg)
+                      const FusedF16Weights* d_blob, int num_cus, hipStream_t s, unsigned long long* dbg)
 {
     if (out_rows <= 0) return;
     const int tiles_x = (W + GW - 1) / GW;
@@ -348,10 +432,10 @@ void launch_fused_f16(const float* Y, int W, int H, int y_row_base, int y_rows, 
     chunks = (out_rows + chunk_rows - 1) / chunk_rows;
     if (dbg)
         hipLaunchKernelGGL(k_fused_f16<true>, dim3(tiles_x * chunks), dim3(NT), L_END, s, Y, W, H, y_row_base, y_rows, out, out_row0,
-                           out_rows, d_blob, chunk_rows, tiles_x, skew, dbg);
+                           out_rows, d_blob, chunk_rows, tiles_x, dbg);
     else
         hipLaunchKernelGGL(k_fused_f16<false>, dim3(tiles_x * chunks), dim3(NT), L_END, s, Y, W, H, y_row_base, y_rows, out, out_row0,
-                           out_rows, d_blob, chunk_rows, tiles_x, skew, dbg);
+                           out_rows, d_blob, chunk_rows, tiles_x, dbg);
 }
 
 }  // namespace srcnn

@@ -37,8 +37,11 @@ struct DevAxisTable {          // device pointers into one uploaded AxisTable
 //                            row (lane%32) = channel 32*blk + lane%32
 //   w2[blk][ks][hl][lane][j] row = output m = lane%32, k = input channel 32*blk + 16*ks + 8*(j/4) + 4*(lane/32) + j%4
 //   w3[ks][hl][lane][j]      row = tap t = lane%32 (dy*5+dx, rows >= 25 zero), k = channel m = 16*ks + 8*(j/4) + 4*(lane/32) + j%4
-//   b1[half][reg], b2[half][reg]  biases in accumulator-register order
-constexpr int FU_NW = 8;      // waves per workgroup of the fused kernel
+//   b1[half][reg], b2[half][reg]  biases x 2^8 in accumulator-register order: the C operand that opens an MFMA chain
+#ifndef FU_NW_DEF
+#define FU_NW_DEF 8
+#endif
+constexpr int FU_NW = FU_NW_DEF;      // waves per workgroup of the fused kernel
 struct FusedF16Weights {
     unsigned short w1[9][2][2][64][8];
     unsigned short w2[2][2][2][64][8];
@@ -52,8 +55,7 @@ struct FusedF16Weights {
 hipError_t upload_weights(const DevWeights& w);
 hipError_t fused_f16_prepare();
 void launch_fused_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* out, int out_row0, int out_rows,
-                      const FusedF16Weights* d_blob, int num_cus, int skew, hipStream_t s,
-                      unsigned long long* dbg = nullptr);
+                      const FusedF16Weights* d_blob, int num_cus, hipStream_t s, unsigned long long* dbg = nullptr);
 
 void launch_resample_cols(const float* src, int w, int src_row_base, float* dst, int dst_row0, int dst_rows,
                           const DevAxisTable& t, hipStream_t s);
