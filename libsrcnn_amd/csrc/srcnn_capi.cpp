@@ -215,14 +215,16 @@ void split_f16_bits(float v, unsigned short& hi, unsigned short& lo)
 void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
 {
     memset(&f, 0, sizeof f);
-    for (int s = 0; s < 9; ++s)
+    for (int s = 0; s < FU_NK; ++s)
         for (int blk = 0; blk < 2; ++blk)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
                     const int ch = 32 * blk + (l & 31), h = l >> 5;
-                    float w = 0.f;
-                    if (h == 0) w = d.w1t[s * 9 + j][ch];
-                    else if (j == 7) w = d.w1t[s * 9 + 8][ch];
+                    int dy = -1, dx = -1;                      // tap carried by this slot (none: weight 0)
+                    if (s < 4) { dy = 2 * s + h; dx = j; }
+                    else if (s == 4) { if (h == 0) { dy = 8; dx = j; } else { dy = j; dx = 8; } }
+                    else if (h == 0 && j == 0) { dy = 8; dx = 8; }
+                    const float w = dy >= 0 ? d.w1t[dy * 9 + dx][ch] : 0.f;
                     split_f16_bits(w, f.w1[s][blk][0][l][j], f.w1[s][blk][1][l][j]);
                 }
     for (int blk = 0; blk < 2; ++blk)

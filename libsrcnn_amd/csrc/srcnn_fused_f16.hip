@@ -10,6 +10,11 @@
 // so their low pieces stay out of the fp16 subnormal range) and every product is hi*hi + hi*lo + lo*hi on
 // v_mfma_f32_32x32x16_f16 with fp32 accumulation -- the error class of an fp32 FMA evaluation.
 //
+// Layer 1 is a [64 x 81] x [81 x px] GEMM.  Its 81 taps are packed into 6 k-steps of 16 slots (96, not 9 x 16 = 144):
+// four k-steps take two window rows each (lanes 0-31 one row, lanes 32-63 the next; taps dx 0..7 = 8 consecutive
+// pixels), the fifth takes window row 8 row-wise and the tap column dx = 8 of rows 0..7 column-wise (16-bit LDS reads
+// with one address per element), the sixth the single remaining tap.  72 + 36 = 108 MFMAs per 2 x 32 pixels.
+//
 // Layer 3 has ONE output channel, which would waste 31/32 of a matrix instruction.  It is therefore evaluated as a
 // 1x1 convolution with 25 outputs -- P[tap][px] = sum_m w3[m][tap] * c2[m][px], a 32(25 used) x 32 x 32 GEMM whose B
 // operand is the layer-2 accumulator tile itself -- followed by a 25-term shifted sum
@@ -41,10 +46,10 @@
 //   * The hi/lo split is 4 instructions per pair of values; only v_fma_mix_f32 is inline asm, both fp16 conversions are
 //     compiler-visible so that every register an MFMA reads was written by an instruction the hazard recogniser sees
 //     (asm feeding an MFMA directly produced wrong results as soon as the scheduler moved the MFMA next to it).
-//   * FU_SEQ=1 (default): per row, layer 1 (108 MFMAs, priority FU_PRIO) then layers 2+3 and the gather (36 MFMAs + all
+//   * FU_SEQ=1 (default): per row, layer 1 (72 MFMAs, priority FU_PRIO) then layers 2+3 and the gather (36 MFMAs + all
 //     the VALU work, priority 0).  The raised priority in the MFMA-only phase makes the two waves of a SIMD complement
 //     each other: without it the older wave wins every arbitration (9.5k vs 16.7k cycles per row, the workgroup waits
-//     for the slow half); with it both run ~11.8k cycles per row = 5.9k per row-wave, 78 % of the MFMA floor (4608).
+//     for the slow half; measured before the K packing); with it the halves run within ~10 % of each other.
 //   * FU_SEQ=0: the previous row's layers 2+3 cut into nine slices and woven into the next row's layer-1 k-steps
 //     (sched_group_barrier).  Needs both accumulator sets: 256 VGPRs spill at two waves per SIMD; with one wave per
 //     SIMD (FU_NW_DEF=4, 428 registers) it runs 7.6k cycles per row -- slower than two simpler waves.  Kept for A/B.
@@ -75,6 +80,7 @@ constexpr int SLOTS = 12, STAGE = 4;             // ring rows / rows per stage (
 constexpr int RING = SLOTS * SB;                 // bytes per wave
 constexpr int PS = 64;                           // P plane stride (floats)
 constexpr int PW = 25 * PS;                      // floats per wave
+constexpr int NK = FU_NK;                        // layer-1 k-steps (81 taps packed into 6 x 16 slots)
 constexpr float F_INV = 1.f / 256.f;             // undoes FusedF16Weights' 2^8 weight scale (exact)
 #ifndef FU_WEAVE
 #define FU_WEAVE 1
@@ -83,7 +89,7 @@ constexpr float F_INV = 1.f / 256.f;             // undoes FusedF16Weights' 2^8 
 #define FU_SEQ 1
 #endif
 #ifndef FU_PRIO
-#define FU_PRIO 2
+#define FU_PRIO 1
 #endif
 
 constexpr int L_W1 = 0;                                          // byte offsets into dynamic LDS
@@ -205,6 +211,9 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // the padding columns of the ring are read (against zero weights) by the last k-step: they must hold finite numbers
+    for (int i = lane; i < RING / 4; i += 64) reinterpret_cast<unsigned*>(Yr)[i] = 0u;
+    wave_sync();
     for (int k = 0; k < SLOTS / STAGE; ++k) { fetch(ubase + STAGE * k); land(ubase + STAGE * k); }
     wave_sync();
     // ---- per-lane constants ----
@@ -217,9 +226,10 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     // LDS byte address (inside a ring slot) of this lane's B fragment for segment 0: staged column q0, from the copy
     // whose alignment suits its parity; segment 1 is +64 B, the lo plane +2*PB.  Kept opaque so that every read below
     // is "one base register + immediate offset".
-    const int q0 = col + half;
+    const int q0 = col;
     unsigned frag_hi = (unsigned)(L_Y + wv * RING + ((q0 & 1) ? PB + 2 * (q0 + 1) : 2 * q0));
-    asm volatile("" : "+v"(frag_hi));
+    unsigned frag_el = (unsigned)(L_Y + wv * RING + 2 * q0);     // element-wise reads: unshifted copy, any alignment
+    asm volatile("" : "+v"(frag_hi), "+v"(frag_el));
 
     float O[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                     // partial sums of output rows v+2 .. v-2
     const int nv = R1 - R0 + 4;                                 // virtual layer-2 rows R0-2 .. R1+1
@@ -240,16 +250,41 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
         }
         int s0 = 0;
         h8 bh[2], bl[2], a0h, a0l, a1h, a1l;
+        auto wrap = [&](int r) { return s0 + r >= SLOTS ? s0 + r - SLOTS : s0 + r; };       // ring slot of window row r
         auto load_step = [&](int s, h8 (&xbh)[2], h8 (&xbl)[2], h8& x0h, h8& x0l, h8& x1h, h8& x1l) {
-            const int slot = s0 + s >= SLOTS ? s0 + s - SLOTS : s0 + s;
-            const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + slot * SB));
-            const unsigned* yl = yh + 2 * PB / 4;
+            if (s < 4) {
+                // window rows 2s (lanes 0-31) and 2s+1 (lanes 32-63), taps dx = 0..7: 8 consecutive halves of one row
+                const unsigned off = (unsigned)((half ? wrap(2 * s + 1) : wrap(2 * s)) * SB);
+                const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + off));
+                const unsigned* yl = yh + 2 * PB / 4;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                u32x4 hi4, lo4;
+                for (int g = 0; g < 2; ++g) {
+                    u32x4 hi4, lo4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
-                xbh[g] = as_h8(hi4); xbl[g] = as_h8(lo4);
+                    for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
+                    xbh[g] = as_h8(hi4); xbl[g] = as_h8(lo4);
+                }
+            } else if (s == 4) {
+                // lanes 0-31: window row 8, taps dx = 0..7 (row-wise); lanes 32-63: tap column dx = 8 of window rows
+                // 0..7 (column-wise).  One address per element and lane, 16-bit reads from the unshifted planes.
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned adr = frag_el + (unsigned)(half ? wrap(j) * SB + 16 : wrap(8) * SB + 2 * j);
+                    const _Float16* e = reinterpret_cast<const _Float16*>(lds_raw + adr);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) { xbh[g][j] = e[32 * g]; xbl[g][j] = e[32 * g + PB]; }
+                }
+            } else {
+                // the 81st tap (8,8) in slot j = 0 of lanes 0-31; every other slot has a zero weight
+                const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + (unsigned)(wrap(8) * SB) + 16));
+                const unsigned* yl = yh + 2 * PB / 4;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    u32x4 hi4, lo4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
+                    xbh[g] = as_h8(hi4); xbl[g] = as_h8(lo4);
+                }
             }
             x0h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 0) * 64 + lane) * 8);
             x0l = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 1) * 64 + lane) * 8);
@@ -347,11 +382,11 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             h8 nbh[2], nbl[2], n0h, n0l, n1h, n1l, fn[2][2] = {};
-            if constexpr (L1) { if (s + 1 < 9) load_step(s + 1, nbh, nbl, n0h, n0l, n1h, n1l); }
+            if constexpr (L1) { if (s + 1 < NK) load_step(s + 1, nbh, nbl, n0h, n0l, n1h, n1l); }
             if (s + 1 < 9) load_units(s + 1, fn);
             __builtin_amdgcn_sched_barrier(0);                  // requests first: they may not sink towards their uses
             slice(s);
-            if constexpr (L1) {
+            if (L1 && s < NK) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh[g], s == 0 ? c1b[0] : nxt[g][0], 0, 0, 0);
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
             }
             __builtin_amdgcn_sched_barrier(0);                  // slices stay with their k-step
             if (s + 1 < 9) {
-                if constexpr (L1) {
+                if (L1 && s + 1 < NK) {
                     bh[0] = nbh[0]; bh[1] = nbh[1]; bl[0] = nbl[0]; bl[1] = nbl[1];
                     a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
                 }
