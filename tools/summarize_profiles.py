@@ -35,7 +35,7 @@ def short(name):
 
 
 lines = ["# rocprofv3 summary `%s` (MI355X, `python3 bench.py`, strict mode, 3840x2160 -> 7680x4320 frames)\n" % tag]
-for sub, title in (("kt", "default bench command (strict headline + its extra legs)"), ("kt_f16", "`bench.py --tier fast_f16` (non-parity fused kernel)")):
+for sub, title in (("kt", "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras` (strict headline; every launch is one 3840x2160 frame)"), ("kt_f16", "`bench.py --tier fast_f16` (non-parity fused kernel)")):
     stats = one(sub + "/**/*_kernel_stats.csv")
     if not stats:
         continue

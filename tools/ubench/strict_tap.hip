@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256, WPS) void k1(float* out, unsigned long long* c
     if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
 
+// software-pipelined forms: the adds consume the PREVIOUS step's products while the next MFMA is in flight.  Two
+// explicit product buffers and two steps per loop trip, so the double buffer is a rename, not 32 v_mov.
 template <int V, int WPS>
 __global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* clk, int iters, float a0)
 {
@@ -68,18 +70,21 @@ __global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* cl
     for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i * 1e-4f;
     __syncthreads();
     float a = a0 + lane * 1e-3f, b = 0.5f + lane * 2e-3f;
-    float acc[32], d[32];
-    for (int i = 0; i < 32; ++i) { acc[i] = 0.f; d[i] = lane * 1e-6f * i; }
+    float acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
     const f32x32 zero = {};
     const float* lp = lds + lane;
-    unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < iters; ++it) {
-        f32x32 nd;
+    f32x32 p0 = zero, p1 = zero;
+    for (int i = 0; i < 32; ++i) p1[i] = lane * 1e-6f * i;
+    auto half_step = [&](f32x32& produce, const f32x32& consume, int it) {
+        float d[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) d[i] = consume[i];
         float na = a, nb = b;
         if constexpr (V != PK_ONLY && V != SC_ONLY) {
             if constexpr (V == PK_PRIO) asm volatile("s_setprio 3");
-            nd = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, zero, 0, 0, 0);
-            asm volatile("" : "+v"(nd));
+            produce = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, zero, 0, 0, 0);
+            asm volatile("" : "+v"(produce));
             if constexpr (V == PK_PRIO) asm volatile("s_setprio 0");
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -111,15 +116,16 @@ __global__ __launch_bounds__(256, WPS) void k(float* out, unsigned long long* cl
             na = lp[(it & 31) * 64]; nb = lp[2048 + (it & 31) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (V != PK_ONLY && V != SC_ONLY) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) d[i] = nd[i];
-        }
         a = na; b = nb;
+    };
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 2) {
+        half_step(p0, p1, it);
+        half_step(p1, p0, it + 1);
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = a + b;
-    for (int i = 0; i < 32; ++i) s += acc[i] + d[i];
+    for (int i = 0; i < 32; ++i) s += acc[i] + p0[i] + p1[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
