@@ -16,6 +16,13 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
+try:
+    import subprocess
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    head = "unknown"
+
+
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     return max(hits, key=os.path.getmtime) if hits else None      # the latest collection wins
@@ -68,7 +75,7 @@ if pmc:
     if k12 and "FETCH_SIZE" in k12 and "WRITE_SIZE" in k12:
         n_out = 7680 * 4320
         fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024
-        rec = {"kernel": "k_conv12_mfma", "tag": tag, "measured_at": "round 2, tools/collect_profiles.sh " + tag,
+        rec = {"kernel": "k_conv12_mfma", "tag": tag, "measured_at": "tools/collect_profiles.sh %s, code at commit %s" % (tag, head),
                "fetch_bytes": fetch, "write_bytes": write,
                "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 132 * n_out,
                "note": "FETCH_SIZE/WRITE_SIZE are KiB, separate passes.  The guide's x2 FETCH correction is for 16 B/lane streams; "
