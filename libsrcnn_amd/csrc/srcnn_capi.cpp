@@ -165,6 +165,7 @@ struct Context {
     int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
     FusedF16Weights* fused_w = nullptr;   // device copy of the fused fp16 kernel's weight image
+    bool resample_two_pass = false;   // SRCNN_RESAMPLE_2PASS=1: always the two separate resampler passes (A/B testing)
     bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
     std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
     unsigned long long table_clock = 0;
@@ -281,6 +282,8 @@ int ensure_init_locked(int device)
         HIP_TRY(fused_f16_prepare());
         const char* uf = getenv("SRCNN_F16_UNFUSED");
         g.f16_unfused = uf && atoi(uf) != 0;
+        const char* r2 = getenv("SRCNN_RESAMPLE_2PASS");
+        g.resample_two_pass = r2 && atoi(r2) != 0;
     }
     g.num_cus = prop.multiProcessorCount;
     const char* sel = getenv("SRCNN_CONV12");
@@ -476,6 +479,7 @@ int resample_rows_range(Call& c, const float* d_in, unsigned sw, unsigned sh, un
         const float* mid = d_in + (size_t)r0 * sw;
         if (sh != dh) {
             if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
+            if (!g.resample_two_pass && launch_resample_2d(d_in, sw, d_dst, dw, r0, r1 - r0, tv->view(), th->view(), s)) return SRCNN_OK;
             if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
             launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, tv->view(), s);
             mid = ws.tmp;

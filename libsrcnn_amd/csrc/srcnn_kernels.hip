@@ -114,6 +114,65 @@ __global__ __launch_bounds__(256) void k_resample_rows_reg(
     }
 }
 
+// Both passes of an up-scale in ONE kernel (vertical first, then horizontal, as src/frawscale.cpp:238-278 orders them):
+// a block owns an R2_TH x R2_TW output tile, runs the vertical pass for exactly the intermediate columns the tile's
+// horizontal taps touch into LDS (fp32, i.e. rounded after the pass like the reference's intermediate image) and then the
+// horizontal pass out of LDS.  Same operations in the same order as k_resample_cols + k_resample_rows_reg -- the
+// intermediate image just never goes to HBM (one launch instead of two, no dst_h x src_w round trip).
+constexpr int R2_TW = 256, R2_TH = 8, R2_LW = R2_TW + 24;       // LDS row: the tile's source-column span (<= TW + taps)
+__global__ __launch_bounds__(R2_TW) void k_resample_2d(
+    const float* __restrict__ src, int src_w, float* __restrict__ dst, int dst_w, int dst_row0, int dst_rows,
+    const int* __restrict__ vfirst, const int* __restrict__ vtaps, const double* __restrict__ vwt, int vstride,
+    const int* __restrict__ hfirst, const int* __restrict__ htaps, const double* __restrict__ hwt, int hstride)
+{
+    __shared__ float mid[R2_TH][R2_LW];
+    __shared__ int span[2];
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x * R2_TW + tid;
+    const int xc = min(x, dst_w - 1);
+    const int s0 = hfirst[xc], n = htaps[xc];
+    if (tid == 0) { span[0] = 0x7fffffff; span[1] = 0; }
+    __syncthreads();
+    atomicMin(&span[0], s0);
+    atomicMax(&span[1], s0 + n);
+    __syncthreads();
+    const int c0 = span[0], cn = min(span[1] - c0, R2_LW);       // host guarantees span <= R2_LW (launch_resample_2d)
+    const int ry0 = blockIdx.y * R2_TH;
+    // ---- vertical pass for rows [ry0, ry0+TH) x source columns [c0, c0+cn) ----
+    for (int r = 0; r < R2_TH; ++r) {
+        const int ry = ry0 + r;
+        if (ry >= dst_rows) break;                                // uniform
+        const int y = dst_row0 + ry;
+        const int v0 = vfirst[y], vn = vtaps[y];
+        const double* wr = vwt + (size_t)y * vstride;
+        for (int c = tid; c < cn; c += R2_TW) {
+            double acc = 0.0;
+            for (int t = 0; t < vn; ++t) {
+                const double px = (double)src[(size_t)(v0 + t) * src_w + c0 + c];
+                acc = acc + wr[t] * px;
+            }
+            mid[r][c] = (float)acc;
+        }
+    }
+    __syncthreads();
+    if (x >= dst_w) return;
+    // ---- horizontal pass out of LDS ----
+    const double* wr = hwt + (size_t)x * hstride;
+    double w[RS_MAXT];
+#pragma unroll
+    for (int t = 0; t < RS_MAXT; ++t) w[t] = t < n ? wr[t] : 0.0;
+    for (int r = 0; r < R2_TH; ++r) {
+        const int ry = ry0 + r;
+        if (ry >= dst_rows) break;
+        const float* in = &mid[r][s0 - c0];
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < RS_MAXT; ++t)
+            if (t < n) acc = acc + w[t] * (double)in[t];
+        dst[(size_t)ry * dst_w + x] = (float)acc;
+    }
+}
+
 // =============================================================================================
 // conv12, VALU-only alternative (SRCNN_CONV12=valu; the production kernel is k_conv12_mfma below):
 // 9x9x1->64 + ReLU, then 1x1x64->32 + ReLU, fused; the 64 intermediate planes of the
@@ -949,6 +1008,18 @@ void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, in
     dim3 grid(cdiv(dst_w, 256), std::min(rows, 65535));
     hipLaunchKernelGGL(k_resample_rows, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
                        t.weight, t.stride);
+}
+
+bool launch_resample_2d(const float* src, int src_w, float* dst, int dst_w, int dst_row0, int dst_rows, const DevAxisTable& tv,
+                        const DevAxisTable& th, hipStream_t s)
+{
+    // only where a tile's horizontal taps span at most R2_LW source columns: up-scales (dst_w >= src_w) with short tables
+    if (dst_rows <= 0 || dst_w < src_w || th.max_taps > RS_MAXT || th.max_taps + R2_TW > R2_LW) return false;
+    dim3 grid(cdiv(dst_w, R2_TW), std::min<unsigned>(cdiv(dst_rows, R2_TH), 65535u * 16u));
+    if (grid.y > 65535u) return false;
+    hipLaunchKernelGGL(k_resample_2d, grid, dim3(R2_TW), 0, s, src, src_w, dst, dst_w, dst_row0, dst_rows, tv.first, tv.taps,
+                       tv.weight, tv.stride, th.first, th.taps, th.weight, th.stride);
+    return true;
 }
 
 void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,

@@ -242,6 +242,24 @@ def test_fused_f16_bands_tiles_and_chunks(srcnn, oracle_lib):
         S.set_mode(prev)
 
 
+def test_fused_f16_strip_and_chunk_edges_sweep(srcnn, oracle_lib):
+    """Seeded sweep of frame shapes whose 2x outputs straddle the fused kernel's decomposition: 60-column wave strips,
+    480-column workgroup strips, 4-row ring stages, 16-row minimum chunks and the 1-/2-row degenerate cases."""
+    S = srcnn
+    rng = np.random.default_rng(2026)
+    widths = [14, 15, 16, 29, 30, 31, 119, 120, 121, 239, 240, 241, 245]
+    heights = [1, 2, 3, 7, 8, 9, 17, 33]
+    shapes = [(int(rng.choice(heights)), int(rng.choice(widths))) for _ in range(16)] + [(1, 241), (33, 1), (2, 30)]
+    prev = S.set_mode(S.MODE_FAST_F16)
+    try:
+        for k, (h, w) in enumerate(shapes):
+            y = synth.plane(h, w, synth.SEED0 + 700 + k, "noise" if k % 2 else "smooth")
+            err = float(np.max(np.abs(S.y_upscale2x(y).astype(np.float64) - oracle_lib.y_path(y))))
+            assert err <= TOL_FAST_F16, (h, w, err)
+    finally:
+        S.set_mode(prev)
+
+
 def test_unfused_f16_path_still_available(oracle_lib, tmp_path):
     """SRCNN_F16_UNFUSED=1 selects the two-kernel form of the tier (k_conv12_f16 + k_conv3_fast) for A/B runs."""
     import os
