@@ -46,10 +46,11 @@
 //   * The hi/lo split is 4 instructions per pair of values; only v_fma_mix_f32 is inline asm, both fp16 conversions are
 //     compiler-visible so that every register an MFMA reads was written by an instruction the hazard recogniser sees
 //     (asm feeding an MFMA directly produced wrong results as soon as the scheduler moved the MFMA next to it).
-//   * FU_SEQ=1 (default): per row, layer 1 (72 MFMAs, priority FU_PRIO) then layers 2+3 and the gather (36 MFMAs + all
-//     the VALU work, priority 0).  The raised priority in the MFMA-only phase makes the two waves of a SIMD complement
-//     each other: without it the older wave wins every arbitration (9.5k vs 16.7k cycles per row, the workgroup waits
-//     for the slow half; measured before the K packing); with it the halves run within ~10 % of each other.
+//   * FU_SEQ=1 (default): per row, layer 1 (72 MFMAs, nothing else) then layers 2+3 and the gather as one region (36
+//     MFMAs + all the VALU work, both segments' chains interleaved), with a higher wave priority in the second phase so
+//     that the two waves of a SIMD complement each other.  Without priorities the older wave wins every arbitration
+//     (9.5k vs 16.7k cycles per row, the workgroup waits for the slow half).  Per row and wave: layer 1 ~4.9-6.0k
+//     cycles, layers 2+3 + gather ~4.0k; the matrix pipe is busy 63-73 % of the time.
 //   * FU_SEQ=0: the previous row's layers 2+3 cut into nine slices and woven into the next row's layer-1 k-steps
 //     (sched_group_barrier).  Needs both accumulator sets: 256 VGPRs spill at two waves per SIMD; with one wave per
 //     SIMD (FU_NW_DEF=4, 428 registers) it runs 7.6k cycles per row -- slower than two simpler waves.  Kept for A/B.
@@ -89,7 +90,10 @@ constexpr float F_INV = 1.f / 256.f;             // undoes FusedF16Weights' 2^8 
 #define FU_SEQ 1
 #endif
 #ifndef FU_PRIO
-#define FU_PRIO 1
+#define FU_PRIO 0      // wave priority in the layer-1 phase
+#endif
+#ifndef FU_PRIO23
+#define FU_PRIO23 2    // ... and in the layers-2+3 phase
 #endif
 
 constexpr int L_W1 = 0;                                          // byte offsets into dynamic LDS
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     auto step = [&](auto DO_L1, auto DO_L23, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], int a_nxt, int v_prev, int row_idx) {
         constexpr bool L1 = decltype(DO_L1)::value, L23 = decltype(DO_L23)::value;
         if constexpr (DIAG) {
-            if (blockIdx.x == 0 && lane == 0 && row_idx < 64 && dbg) dbg[((size_t)wv * 64 + row_idx) * 4] = __builtin_amdgcn_s_memtime();
+            if (L1 && blockIdx.x == 0 && lane == 0 && row_idx < 64 && dbg) dbg[((size_t)wv * 64 + row_idx) * 4] = __builtin_amdgcn_s_memtime();
         }
         int s0 = 0;
         h8 bh[2], bl[2], a0h, a0l, a1h, a1l;
@@ -416,6 +420,73 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
             }
         }
     };
+    // Layers 2+3, the P hand-over and the gather of one row as ONE scheduling region (sequential form): all W2/W3
+    // fragments are requested up front (both segments share them: 12 ds_read_b128), and the two segments' accumulator
+    // chains are interleaved unit by unit, so one chain's conversions run in the shadow of the other chain's MFMAs.
+    auto l23 = [&](f32x16 (&cur)[2][2], int v_prev) {
+        h8 w2h[2][2], w2l[2][2], w3h[2], w3l[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                w2h[blk][ks] = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 0) * 64 + lane) * 8);
+                w2l[blk][ks] = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 1) * 64 + lane) * 8);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            w3h[ks] = *reinterpret_cast<const h8*>(W3f + ((ks * 2 + 0) * 64 + lane) * 8);
+            w3l[ks] = *reinterpret_cast<const h8*>(W3f + ((ks * 2 + 1) * 64 + lane) * 8);
+        }
+        const f32x16 c2b = *reinterpret_cast<const f32x16*>(B2s + half * 16);
+        f32x16 acc2[2], accp[2] = {};
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(cur[g][blk][8 * ks + j] * F_INV, 0.f);
+                    h8 xh, xl;
+                    split8(x, xh, xl);
+                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[blk][ks], xh, (blk | ks) ? acc2[g] : c2b, 0, 0, 0);
+                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[blk][ks], xl, acc2[g], 0, 0, 0);
+                    acc2[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[blk][ks], xh, acc2[g], 0, 0, 0);
+                }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = fmaxf(acc2[g][8 * ks + j] * F_INV, 0.f);
+                h8 xh, xl;
+                split8(x, xh, xl);
+                accp[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3h[ks], xh, accp[g], 0, 0, 0);
+                accp[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3h[ks], xl, accp[g], 0, 0, 0);
+                accp[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3l[ks], xh, accp[g], 0, 0, 0);
+            }
+        // P rows: register r of half h is tap 8*(r/4) + 4h + r%4; taps >= 25 are padding
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 13; ++r) {
+                const int t0 = 8 * (r >> 2) + (r & 3);
+                if (r < 12 || half == 0) Pw[(t0 + 4 * half) * PS + 32 * g + col] = accp[g][r] * F_INV;
+            }
+        wave_sync();
+        // layer-3 gather: layer-2 row v feeds output rows v+2-dy with tap row dy
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) O[dy] += Pw[(dy * 5 + dx) * PS + pidx[dx]];
+        const int orow = v_prev - 2;                            // complete: its last contribution was tap row 4
+        if (orow >= R0 && ox_ok) out[(size_t)(orow - out_row0) * W + ox] = fminf(fmaxf(O[4] + b3, 0.f), 255.f);
+        O[4] = O[3]; O[3] = O[2]; O[2] = O[1]; O[1] = O[0]; O[0] = 0.f;
+        __builtin_amdgcn_wave_barrier();                        // the next row overwrites Pw
+    };
+
     using T = std::true_type;
     using F = std::false_type;
     auto row_of = [&](int k) { return clampi(R0 - 2 + k, 0, H - 1); };    // the reference clamps layer-2 ACTIVATIONS at the border
@@ -424,12 +495,18 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     // sequential form (A/B experiment): layer 1 of a row, then its layers 2+3 -- no cross-row overlap, half the accumulators
 #pragma unroll 1
     for (int k = 0; k < nv; ++k) {
-        // The wave in its MFMA-only phase outranks its SIMD partner, whose VALU-heavy phase then runs in the shadows of
-        // those MFMAs (without this the older wave of the pair simply wins every arbitration: 9.5k vs 16.7k cycles/row)
+        // Phase-dependent priority.  Without it the older wave of a SIMD pair wins every arbitration (9.5k vs 16.7k
+        // cycles per row; the workgroup waits for the starved half).  The wave in the layers-2+3 phase -- few MFMAs, each
+        // at the end of a conversion chain -- outranks its partner; the partner's MFMA-only layer 1 fills every other
+        // slot of the matrix pipe.  (The opposite assignment also balances the pair but is 2-5 % slower: the conversion
+        // chains then wait behind 72 back-to-back MFMAs.)
         __builtin_amdgcn_s_setprio(FU_PRIO);
         step(T{}, F{}, accB, accA, row_of(k), 0, k);
-        __builtin_amdgcn_s_setprio(0);
-        step(F{}, T{}, accA, accB, 0, R0 - 2 + k, k);
+        __builtin_amdgcn_s_setprio(FU_PRIO23);
+        if constexpr (DIAG) {           // phase boundary stamp (after the last layer-1 MFMA has been issued)
+            if (blockIdx.x == 0 && lane == 0 && k < 64 && dbg) dbg[((size_t)wv * 64 + k) * 4 + 1] = __builtin_amdgcn_s_memtime();
+        }
+        l23(accA, R0 - 2 + k);
     }
 #else
     step(T{}, F{}, accB, accA, row_of(0), 0, 0);                           // prologue: layer 1 of the first row -> accA

@@ -22,5 +22,7 @@ for it in range(3):
 t = d_dbg.to_numpy(np.uint64, (8, 64, 4)).astype(np.int64)
 for wv in range(8):
     row = np.diff(t[wv, 8:56, 0])
-    print("wave %d: row period median %6.0f  min %6.0f  max %6.0f cycles; start offset vs wave 0 at row 8: %7d" %
-          (wv, np.median(row), row.min(), row.max(), int(t[wv, 8, 0] - t[0, 8, 0])))
+    l1 = t[wv, 8:55, 1] - t[wv, 8:55, 0]
+    l23 = t[wv, 9:56, 0] - t[wv, 8:55, 1]
+    print("wave %d: row period median %6.0f  min %6.0f  max %6.0f cycles | layer 1 %6.0f  layers 2+3+gather %6.0f | start offset vs wave 0 at row 8: %7d" %
+          (wv, np.median(row), row.min(), row.max(), np.median(l1), np.median(l23), int(t[wv, 8, 0] - t[0, 8, 0])))
