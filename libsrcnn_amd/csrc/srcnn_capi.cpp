@@ -1168,7 +1168,8 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     for (unsigned b = 0; b <= nb; ++b) r0s[b] = (unsigned)((unsigned long long)dh * b / nb);
     for (unsigned b = 0; b < nb; ++b) max_band = std::max(max_band, r0s[b + 1] - r0s[b]);
     // size the band scratch once, for the largest band plus its halos, so no band re-allocates mid-pipeline
-    if ((rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
+    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !g.f16_unfused;           // the fused kernel has no layer-2 planes
+    if (!no_planes && (rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
     if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * std::min(dh, max_band + 12)))) return rc;
     if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
     const int dev = g.device;

@@ -34,7 +34,7 @@ def short(name):
         tier = " [strict]"
     elif "<false" in name:
         tier = " [fast tier]"
-    for key in ("k_fused_f16", "k_conv12_f16", "k_conv12_mfma", "k_conv12", "k_conv3_fast", "k_conv3", "k_resample_rows", "k_resample_cols", "k_rgb_split",
+    for key in ("k_fused_f16", "k_conv12_f16", "k_conv12_mfma", "k_conv12", "k_conv3_fast", "k_conv3", "k_resample_2d", "k_resample_rows", "k_resample_cols", "k_rgb_split",
                 "k_ycc_merge"):
         if key in name:
             return key + (" [fast tier]" if key in ("k_fused_f16", "k_conv12_f16", "k_conv3_fast") else tier)
