@@ -479,7 +479,7 @@ int resample_rows_range(Call& c, const float* d_in, unsigned sw, unsigned sh, un
         const float* mid = d_in + (size_t)r0 * sw;
         if (sh != dh) {
             if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
-            if (!g.resample_two_pass && launch_resample_2d(d_in, sw, d_dst, dw, r0, r1 - r0, tv->view(), th->view(), s)) return SRCNN_OK;
+            if (!g.resample_two_pass && launch_resample_2d(d_in, sw, sh, d_dst, dw, dh, r0, r1 - r0, tv->view(), th->view(), s)) return SRCNN_OK;
             if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
             launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, tv->view(), s);
             mid = ws.tmp;

@@ -66,8 +66,8 @@ void launch_resample_cols(const float* src, int w, int src_row_base, float* dst,
 void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, int rows, const DevAxisTable& t,
                           hipStream_t s);
 // both passes of an up-scale in one kernel; returns false (nothing launched) when the shape does not qualify
-bool launch_resample_2d(const float* src, int src_w, float* dst, int dst_w, int dst_row0, int dst_rows, const DevAxisTable& tv,
-                        const DevAxisTable& th, hipStream_t s);
+bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
+                        const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s);
 void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                    int out_rows, bool strict, hipStream_t s);
 hipError_t conv12_mfma_prepare();

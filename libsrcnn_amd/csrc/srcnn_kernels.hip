@@ -120,56 +120,79 @@ __global__ __launch_bounds__(256) void k_resample_rows_reg(
 // horizontal pass out of LDS.  Same operations in the same order as k_resample_cols + k_resample_rows_reg -- the
 // intermediate image just never goes to HBM (one launch instead of two, no dst_h x src_w round trip).
 constexpr int R2_TW = 256, R2_TH = 8, R2_LW = R2_TW + 24;       // LDS row: the tile's source-column span (<= TW + taps)
+constexpr int R2_SR = R2_TH + RS_MAXT;                          // source rows a tile's vertical taps can touch (up-scale)
 __global__ __launch_bounds__(R2_TW) void k_resample_2d(
     const float* __restrict__ src, int src_w, float* __restrict__ dst, int dst_w, int dst_row0, int dst_rows,
     const int* __restrict__ vfirst, const int* __restrict__ vtaps, const double* __restrict__ vwt, int vstride,
     const int* __restrict__ hfirst, const int* __restrict__ htaps, const double* __restrict__ hwt, int hstride)
 {
-    __shared__ float mid[R2_TH][R2_LW];
-    __shared__ int span[2];
+    // Every global load of the block is issued in ONE batch (tables, then the source patch); the two passes then run
+    // out of LDS.  (A first version read its sources row by row behind dependent table loads and was latency-bound.)
+    __shared__ float raw[R2_SR][R2_LW];       // source patch: rows [vmin, vmax) x columns [c0, c0+cn)
+    __shared__ float mid[R2_TH][R2_LW];       // after the vertical pass (fp32, like the reference's intermediate image)
+    __shared__ double vw[R2_TH][RS_MAXT];
+    __shared__ int vf[R2_TH], vn[R2_TH];
+    __shared__ int span[4];                   // min first_h, max (first_h + taps_h), min first_v, max (first_v + taps_v)
     const int tid = threadIdx.x;
     const int x = blockIdx.x * R2_TW + tid;
     const int xc = min(x, dst_w - 1);
     const int s0 = hfirst[xc], n = htaps[xc];
-    if (tid == 0) { span[0] = 0x7fffffff; span[1] = 0; }
-    __syncthreads();
-    atomicMin(&span[0], s0);
-    atomicMax(&span[1], s0 + n);
-    __syncthreads();
-    const int c0 = span[0], cn = min(span[1] - c0, R2_LW);       // host guarantees span <= R2_LW (launch_resample_2d)
     const int ry0 = blockIdx.y * R2_TH;
-    // ---- vertical pass for rows [ry0, ry0+TH) x source columns [c0, c0+cn) ----
-    for (int r = 0; r < R2_TH; ++r) {
-        const int ry = ry0 + r;
-        if (ry >= dst_rows) break;                                // uniform
-        const int y = dst_row0 + ry;
-        const int v0 = vfirst[y], vn = vtaps[y];
-        const double* wr = vwt + (size_t)y * vstride;
+    const int rows = min(R2_TH, dst_rows - ry0);
+    if (tid == 0) { span[0] = 0x7fffffff; span[1] = 0; span[2] = 0x7fffffff; span[3] = 0; }
+    __syncthreads();
+    if (tid < R2_TH * RS_MAXT) {
+        const int r = tid / RS_MAXT, t = tid - r * RS_MAXT;
+        if (r < rows) {
+            const int y = dst_row0 + ry0 + r;
+            const int cnt = vtaps[y];
+            vw[r][t] = t < cnt ? vwt[(size_t)y * vstride + t] : 0.0;
+            if (t == 0) {
+                const int f = vfirst[y];
+                vf[r] = f; vn[r] = cnt;
+                atomicMin(&span[2], f);
+                atomicMax(&span[3], f + cnt);
+            }
+        }
+    }
+    {   // column span of the tile: reduce inside the wave first (256 LDS atomics on one address cost microseconds)
+        int lo = s0, hi = s0 + n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if ((tid & 63) == 0) { atomicMin(&span[0], lo); atomicMax(&span[1], hi); }
+    }
+    // the horizontal weights of this thread's column: independent of everything above, so requested now
+    const double* wr = hwt + (size_t)xc * hstride;
+    double w[RS_MAXT];
+#pragma unroll
+    for (int t = 0; t < RS_MAXT; ++t) w[t] = t < n ? wr[t] : 0.0;
+    __syncthreads();
+    const int c0 = span[0], cn = min(span[1] - c0, R2_LW);       // host guarantees both spans fit (launch_resample_2d)
+    const int vmin = span[2], nsrc = min(span[3] - vmin, R2_SR);
+    for (int r = 0; r < nsrc; ++r) {
+        const float* row = src + (size_t)(vmin + r) * src_w + c0;
+        for (int c = tid; c < cn; c += R2_TW) raw[r][c] = row[c];
+    }
+    __syncthreads();
+    // ---- vertical pass: same products, same order as k_resample_cols ----
+    for (int r = 0; r < rows; ++r) {
+        const int rb = vf[r] - vmin, cnt = vn[r];
         for (int c = tid; c < cn; c += R2_TW) {
             double acc = 0.0;
-            for (int t = 0; t < vn; ++t) {
-                const double px = (double)src[(size_t)(v0 + t) * src_w + c0 + c];
-                acc = acc + wr[t] * px;
-            }
+            for (int t = 0; t < cnt; ++t) acc = acc + vw[r][t] * (double)raw[rb + t][c];
             mid[r][c] = (float)acc;
         }
     }
     __syncthreads();
     if (x >= dst_w) return;
-    // ---- horizontal pass out of LDS ----
-    const double* wr = hwt + (size_t)x * hstride;
-    double w[RS_MAXT];
-#pragma unroll
-    for (int t = 0; t < RS_MAXT; ++t) w[t] = t < n ? wr[t] : 0.0;
-    for (int r = 0; r < R2_TH; ++r) {
-        const int ry = ry0 + r;
-        if (ry >= dst_rows) break;
+    // ---- horizontal pass: same as k_resample_rows_reg ----
+    for (int r = 0; r < rows; ++r) {
         const float* in = &mid[r][s0 - c0];
         double acc = 0.0;
 #pragma unroll
         for (int t = 0; t < RS_MAXT; ++t)
             if (t < n) acc = acc + w[t] * (double)in[t];
-        dst[(size_t)ry * dst_w + x] = (float)acc;
+        dst[(size_t)(ry0 + r) * dst_w + x] = (float)acc;
     }
 }
 
@@ -1010,11 +1033,12 @@ void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, in
                        t.weight, t.stride);
 }
 
-bool launch_resample_2d(const float* src, int src_w, float* dst, int dst_w, int dst_row0, int dst_rows, const DevAxisTable& tv,
-                        const DevAxisTable& th, hipStream_t s)
+bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
+                        const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s)
 {
-    // only where a tile's horizontal taps span at most R2_LW source columns: up-scales (dst_w >= src_w) with short tables
-    if (dst_rows <= 0 || dst_w < src_w || th.max_taps > RS_MAXT || th.max_taps + R2_TW > R2_LW) return false;
+    // only where a tile's taps span at most R2_LW source columns and R2_SR source rows: up-scales in both axes with short tables
+    if (dst_rows <= 0 || dst_w < src_w || dst_h < src_h || th.max_taps > RS_MAXT || tv.max_taps > RS_MAXT || th.max_taps + R2_TW > R2_LW)
+        return false;
     dim3 grid(cdiv(dst_w, R2_TW), std::min<unsigned>(cdiv(dst_rows, R2_TH), 65535u * 16u));
     if (grid.y > 65535u) return false;
     hipLaunchKernelGGL(k_resample_2d, grid, dim3(R2_TW), 0, s, src, src_w, dst, dst_w, dst_row0, dst_rows, tv.first, tv.taps,
