@@ -223,8 +223,7 @@ void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
                     const int ch = 32 * blk + (l & 31), h = l >> 5;
                     int dy = -1, dx = -1;                      // tap carried by this slot (none: weight 0)
                     if (s < 4) { dy = 2 * s + h; dx = j; }
-                    else if (s == 4) { if (h == 0) { dy = 8; dx = j; } else { dy = j; dx = 8; } }
-                    else if (h == 0 && j == 0) { dy = 8; dx = 8; }
+                    else { if (h == 0) { dy = 8; dx = j; } else { dy = j; dx = 8; } }
                     const float w = dy >= 0 ? d.w1t[dy * 9 + dx][ch] : 0.f;
                     split_f16_bits(w, f.w1[s][blk][0][l][j], f.w1[s][blk][1][l][j]);
                 }
@@ -246,6 +245,7 @@ void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
     for (int hf = 0; hf < 2; ++hf) {
         for (int r = 0; r < 32; ++r) f.b1[hf * 32 + r] = 256.f * d.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
         for (int r = 0; r < 16; ++r) f.b2[hf * 16 + r] = 256.f * d.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
+        for (int r = 0; r < 32; ++r) f.w88[hf * 32 + r] = 256.f * d.w1t[80][32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
     }
     f.b3 = d.b3;
 }

@@ -10,10 +10,11 @@
 // so their low pieces stay out of the fp16 subnormal range) and every product is hi*hi + hi*lo + lo*hi on
 // v_mfma_f32_32x32x16_f16 with fp32 accumulation -- the error class of an fp32 FMA evaluation.
 //
-// Layer 1 is a [64 x 81] x [81 x px] GEMM.  Its 81 taps are packed into 6 k-steps of 16 slots (96, not 9 x 16 = 144):
+// Layer 1 is a [64 x 81] x [81 x px] GEMM.  80 of its 81 taps are packed into 5 k-steps of 16 slots (not 9 x 16 = 144):
 // four k-steps take two window rows each (lanes 0-31 one row, lanes 32-63 the next; taps dx 0..7 = 8 consecutive
 // pixels), the fifth takes window row 8 row-wise and the tap column dx = 8 of rows 0..7 column-wise (16-bit LDS reads
-// with one address per element), the sixth the single remaining tap.  72 + 36 = 108 MFMAs per 2 x 32 pixels.
+// with one address per element).  The 81st tap (8,8) is an exact fp32 FMA into the C operand that opens the chains,
+// next to the bias.  60 + 36 = 96 MFMAs per 2 x 32 pixels.
 //
 // Layer 3 has ONE output channel, which would waste 31/32 of a matrix instruction.  It is therefore evaluated as a
 // 1x1 convolution with 25 outputs -- P[tap][px] = sum_m w3[m][tap] * c2[m][px], a 32(25 used) x 32 x 32 GEMM whose B
@@ -46,7 +47,7 @@
 //   * The hi/lo split is 4 instructions per pair of values; only v_fma_mix_f32 is inline asm, both fp16 conversions are
 //     compiler-visible so that every register an MFMA reads was written by an instruction the hazard recogniser sees
 //     (asm feeding an MFMA directly produced wrong results as soon as the scheduler moved the MFMA next to it).
-//   * FU_SEQ=1 (default): per row, layer 1 (72 MFMAs, nothing else) then layers 2+3 and the gather as one region (36
+//   * FU_SEQ=1 (default): per row, layer 1 (60 MFMAs + the 64 FMAs of the 81st tap) then layers 2+3 and the gather as one region (36
 //     MFMAs + all the VALU work, both segments' chains interleaved), with a higher wave priority in the second phase so
 //     that the two waves of a SIMD complement each other.  Without priorities the older wave wins every arbitration
 //     (9.5k vs 16.7k cycles per row, the workgroup waits for the slow half).  Per row and wave: layer 1 ~4.9-6.0k
@@ -81,7 +82,7 @@ constexpr int SLOTS = 12, STAGE = 4;             // ring rows / rows per stage (
 constexpr int RING = SLOTS * SB;                 // bytes per wave
 constexpr int PS = 64;                           // P plane stride (floats)
 constexpr int PW = 25 * PS;                      // floats per wave
-constexpr int NK = FU_NK;                        // layer-1 k-steps (81 taps packed into 6 x 16 slots)
+constexpr int NK = FU_NK;                        // layer-1 k-steps (80 taps in 5 x 16 slots; the 81st is an fp32 FMA)
 constexpr float F_INV = 1.f / 256.f;             // undoes FusedF16Weights' 2^8 weight scale (exact)
 #ifndef FU_WEAVE
 #define FU_WEAVE 1
@@ -101,12 +102,14 @@ constexpr int L_W2 = L_W1 + (int)sizeof(FusedF16Weights::w1);
 constexpr int L_W3 = L_W2 + (int)sizeof(FusedF16Weights::w2);
 constexpr int L_B1 = L_W3 + (int)sizeof(FusedF16Weights::w3);
 constexpr int L_B2 = L_B1 + 64 * 4;
-constexpr int L_Y = L_B2 + 32 * 4;
+constexpr int L_W88 = L_B2 + 32 * 4;
+constexpr int L_Y = L_W88 + 64 * 4;
 constexpr int L_P = L_Y + NW * RING;
 constexpr int L_END = L_P + NW * PW * 4;
 static_assert(L_Y % 16 == 0 && L_P % 16 == 0, "alignment");
 static_assert(L_END <= 160 * 1024, "LDS budget");
-static_assert(offsetof(FusedF16Weights, b1) == L_B1 && offsetof(FusedF16Weights, b2) == L_B2, "blob head == LDS image");
+static_assert(offsetof(FusedF16Weights, b1) == L_B1 && offsetof(FusedF16Weights, b2) == L_B2 &&
+              offsetof(FusedF16Weights, w88) == L_W88 && offsetof(FusedF16Weights, b3) == L_Y, "blob head == LDS image");
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     const _Float16* W3f = reinterpret_cast<const _Float16*>(lds_raw + L_W3);
     const float* B1s = reinterpret_cast<const float*>(lds_raw + L_B1);     // biases stay in LDS: 48 VGPRs are worth more
     const float* B2s = reinterpret_cast<const float*>(lds_raw + L_B2);
+    const float* W88s = reinterpret_cast<const float*>(lds_raw + L_W88);
     float* Pall = reinterpret_cast<float*>(lds_raw + L_P);
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // the padding columns of the ring are read (against zero weights) by the last k-step: they must hold finite numbers
+    // defensive: no fragment reads the ring's padding columns, but if one ever did (against zero weights) it must see
+    // finite numbers, not whatever the previous kernel left in LDS
     for (int i = lane; i < RING / 4; i += 64) reinterpret_cast<unsigned*>(Yr)[i] = 0u;
     wave_sync();
     for (int k = 0; k < SLOTS / STAGE; ++k) { fetch(ubase + STAGE * k); land(ubase + STAGE * k); }
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                     for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
                     xbh[g] = as_h8(hi4); xbl[g] = as_h8(lo4);
                 }
-            } else if (s == 4) {
+            } else {
                 // lanes 0-31: window row 8, taps dx = 0..7 (row-wise); lanes 32-63: tap column dx = 8 of window rows
                 // 0..7 (column-wise).  One address per element and lane, 16-bit reads from the unshifted planes.
 #pragma unroll
@@ -277,17 +282,6 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                     const _Float16* e = reinterpret_cast<const _Float16*>(lds_raw + adr);
 #pragma unroll
                     for (int g = 0; g < 2; ++g) { xbh[g][j] = e[32 * g]; xbl[g][j] = e[32 * g + PB]; }
-                }
-            } else {
-                // the 81st tap (8,8) in slot j = 0 of lanes 0-31; every other slot has a zero weight
-                const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + (unsigned)(wrap(8) * SB) + 16));
-                const unsigned* yl = yh + 2 * PB / 4;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    u32x4 hi4, lo4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
-                    xbh[g] = as_h8(hi4); xbl[g] = as_h8(lo4);
                 }
             }
             x0h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 0) * 64 + lane) * 8);
@@ -318,7 +312,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                 }
             }
         };
-        f32x16 c1b[2] = {}, c2b = {};                            // biases (x 2^8), used as the C operand that opens a chain
+        f32x16 c1b[2][2] = {}, c2b = {};                         // the C operands that open the chains (biases x 2^8 ...)
         h8 fa[2][2] = {};
         if constexpr (L1) {
             if (((a_nxt - A0) >> 2) > st_cur) {                 // the row opens the next ring stage (uniform branch)
@@ -330,8 +324,20 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
             }
             s0 = mod12(a_nxt - 4 - ubase);                      // ring slot of the first window row (uniform)
             load_step(0, bh, bl, a0h, a0l, a1h, a1l);
-            c1b[0] = *reinterpret_cast<const f32x16*>(B1s + half * 32);
-            c1b[1] = *reinterpret_cast<const f32x16*>(B1s + half * 32 + 16);
+            // chain openers: bias + the 81st tap (8,8) as an exact fp32 FMA -- y88 = this lane's pixel of window row 8 at
+            // dx = 8, rebuilt from its two fp16 pieces; 64 FMAs in a phase whose VALU slots are otherwise idle
+            const _Float16* e88 = reinterpret_cast<const _Float16*>(lds_raw + (frag_el + (unsigned)(wrap(8) * SB) + 16));
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const f32x16 bias = *reinterpret_cast<const f32x16*>(B1s + half * 32 + 16 * blk);
+                const f32x16 w88 = *reinterpret_cast<const f32x16*>(W88s + half * 32 + 16 * blk);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float y88 = (float)e88[32 * g] + (float)e88[32 * g + PB];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c1b[g][blk][r] = __builtin_fmaf(w88[r], y88, bias[r]);
+                }
+            }
         }
         if constexpr (L23) c2b = *reinterpret_cast<const f32x16*>(B2s + half * 16);
         load_units(0, fa);
@@ -393,8 +399,8 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
             if (L1 && s < NK) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh[g], s == 0 ? c1b[0] : nxt[g][0], 0, 0, 0);
-                    nxt[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh[g], s == 0 ? c1b[1] : nxt[g][1], 0, 0, 0);
+                    nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh[g], s == 0 ? c1b[g][0] : nxt[g][0], 0, 0, 0);
+                    nxt[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh[g], s == 0 ? c1b[g][1] : nxt[g][1], 0, 0, 0);
                     nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl[g], nxt[g][0], 0, 0, 0);
                     nxt[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl[g], nxt[g][1], 0, 0, 0);
                     nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh[g], nxt[g][0], 0, 0, 0);

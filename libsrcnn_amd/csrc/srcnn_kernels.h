@@ -33,10 +33,12 @@ struct DevAxisTable {          // device pointers into one uploaded AxisTable
 // Weight image of the fused fp16 kernel (srcnn_fused_f16.hip): every fp32 weight, pre-scaled by 2^8, split into
 // fp16 hi + lo and laid out in MFMA A-fragment order (lane-major, 8 halves per lane per fragment), built once on the
 // host.  The struct is byte-for-byte what the kernel copies into LDS.
-//   w1[s][blk][hl][lane][j]  the 81 taps packed into FU_NK = 6 k-steps of 16 slots (8 per lane half):
+//   w1[s][blk][hl][lane][j]  80 of the 81 taps packed into FU_NK = 5 k-steps of 16 slots (8 per lane half):
 //                              s = 0..3: lanes 0-31 window row 2s, lanes 32-63 window row 2s+1, tap dx = j
 //                              s = 4:    lanes 0-31 window row 8, dx = j;  lanes 32-63 window row j, dx = 8
-//                              s = 5:    lanes 0-31 slot j = 0 holds tap (8,8); everything else zero
+//   w88[half][reg]           the 81st tap (8,8) x 2^8 as plain fp32, in accumulator-register order: it enters as an
+//                            fp32 FMA into the C operand that opens the layer-1 chains (a sixth k-step for one tap would
+//                            cost 12 MFMAs per 64 pixels; the FMAs ride in the MFMA-only phase's idle VALU slots)
 //                            row (lane%32) = channel 32*blk + lane%32
 //   w2[blk][ks][hl][lane][j] row = output m = lane%32, k = input channel 32*blk + 16*ks + 8*(j/4) + 4*(lane/32) + j%4
 //   w3[ks][hl][lane][j]      row = tap t = lane%32 (dy*5+dx, rows >= 25 zero), k = channel m = 16*ks + 8*(j/4) + 4*(lane/32) + j%4
@@ -44,7 +46,7 @@ struct DevAxisTable {          // device pointers into one uploaded AxisTable
 #ifndef FU_NW_DEF
 #define FU_NW_DEF 8
 #endif
-constexpr int FU_NK = 6;      // layer-1 k-steps of the fused kernel
+constexpr int FU_NK = 5;      // layer-1 k-steps of the fused kernel
 constexpr int FU_NW = FU_NW_DEF;      // waves per workgroup of the fused kernel
 struct FusedF16Weights {
     unsigned short w1[FU_NK][2][2][64][8];
@@ -52,6 +54,7 @@ struct FusedF16Weights {
     unsigned short w3[2][2][64][8];
     float b1[64];
     float b2[32];
+    float w88[64];
     float b3;
     float pad_[3];
 };

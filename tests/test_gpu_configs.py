@@ -260,6 +260,29 @@ def test_fused_f16_strip_and_chunk_edges_sweep(srcnn, oracle_lib):
         S.set_mode(prev)
 
 
+def test_fast_tiers_through_processsrcnn_differ_by_at_most_one_level(srcnn, oracle_lib):
+    """What a ProcessSRCNN user sees when opting into a non-parity tier: the u8 image equals the reference's except where
+    a |dY| of a few 1e-4 moves a value across an integer boundary before truncation -- never by more than one level, and
+    in well under 1 % of the bytes (strict mode: zero bytes)."""
+    S = srcnn
+    img = _image(300, 420, 3, 77)
+    want_rgb, want_conv = oracle_lib.process(img, 2.0)
+    S.ConfigureFilterSRCNN(S.SRCNNF_Bicubic, False)
+    for mode in (S.MODE_FAST, S.MODE_FAST_F16):
+        prev = S.set_mode(mode)
+        try:
+            rc, out, conv = S.ProcessSRCNN(img, 420, 300, 3, 2.0)
+        finally:
+            S.set_mode(prev)
+        assert rc == 0
+        for got, want in ((out.reshape(want_rgb.shape), want_rgb), (conv.reshape(want_conv.shape), want_conv)):
+            d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+            assert int(d.max()) <= 1, (mode, int(d.max()))
+            assert float((d > 0).mean()) < 0.01, (mode, float((d > 0).mean()))
+    rc, out, conv = S.ProcessSRCNN(img, 420, 300, 3, 2.0)
+    assert np.array_equal(out.reshape(want_rgb.shape), want_rgb) and np.array_equal(conv.reshape(want_conv.shape), want_conv)
+
+
 def test_unfused_f16_path_still_available(oracle_lib, tmp_path):
     """SRCNN_F16_UNFUSED=1 selects the two-kernel form of the tier (k_conv12_f16 + k_conv3_fast) for A/B runs."""
     import os
