@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
 #pragma unroll
             for (int r = 0; r < 13; ++r) {
                 const int t0 = 8 * (r >> 2) + (r & 3);
-                if (r < 12 || half == 0) Pw[(t0 + 4 * half) * PS + 32 * g + col] = accp[g][r] * F_INV;
+                if (r < 12 || half == 0) Pw[(t0 + 4 * half) * PS + 32 * g + col] = accp[g][r];       // x 2^8; undone once per output pixel
             }
         };
         auto slice = [&](int s) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                 }
                 if (s == 8) {
                     const int orow = v_prev - 2;                // complete: its last contribution was tap row 4
-                    if (orow >= R0 && ox_ok) out[(size_t)(orow - out_row0) * W + ox] = fminf(fmaxf(O[4] + b3, 0.f), 255.f);
+                    if (orow >= R0 && ox_ok) out[(size_t)(orow - out_row0) * W + ox] = fminf(fmaxf(__builtin_fmaf(O[4], F_INV, b3), 0.f), 255.f);
                     O[4] = O[3]; O[3] = O[2]; O[2] = O[1]; O[1] = O[0]; O[0] = 0.f;
                     __builtin_amdgcn_wave_barrier();            // the next row overwrites Pw
                 }
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
 #pragma unroll
             for (int r = 0; r < 13; ++r) {
                 const int t0 = 8 * (r >> 2) + (r & 3);
-                if (r < 12 || half == 0) Pw[(t0 + 4 * half) * PS + 32 * g + col] = accp[g][r] * F_INV;
+                if (r < 12 || half == 0) Pw[(t0 + 4 * half) * PS + 32 * g + col] = accp[g][r];       // x 2^8; undone once per output pixel
             }
         wave_sync();
         // layer-3 gather: layer-2 row v feeds output rows v+2-dy with tap row dy
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) O[dy] += Pw[(dy * 5 + dx) * PS + pidx[dx]];
         const int orow = v_prev - 2;                            // complete: its last contribution was tap row 4
-        if (orow >= R0 && ox_ok) out[(size_t)(orow - out_row0) * W + ox] = fminf(fmaxf(O[4] + b3, 0.f), 255.f);
+        if (orow >= R0 && ox_ok) out[(size_t)(orow - out_row0) * W + ox] = fminf(fmaxf(__builtin_fmaf(O[4], F_INV, b3), 0.f), 255.f);
         O[4] = O[3]; O[3] = O[2]; O[2] = O[1]; O[1] = O[0]; O[0] = 0.f;
         __builtin_amdgcn_wave_barrier();                        // the next row overwrites Pw
     };
