@@ -73,14 +73,18 @@ namespace {
 
 constexpr int NW = FU_NW;                        // waves per workgroup
 constexpr int NT = 64 * NW;
-constexpr int OW = 60;                           // output columns per wave
+#ifndef FU_SEG
+#define FU_SEG 2
+#endif
+constexpr int SEG = FU_SEG;                      // 32-pixel MFMA segments per wave (layer-2 columns = 32 * SEG)
+constexpr int OW = 32 * SEG - 4;                 // output columns per wave
 constexpr int GW = NW * OW;                      // output columns per workgroup
-constexpr int TWW = 72;                          // staged Y columns per wave: 64 layer-2 columns +-4
-constexpr int PB = 160;                          // bytes per ring plane row: 80 halves >= TWW + 1 (shifted copy) + 7
+constexpr int TWW = 32 * SEG + 8;                // staged Y columns per wave: the layer-2 columns +-4
+constexpr int PB = 2 * (TWW + 8);                // bytes per ring plane row: TWW + 1 (shifted copy) + 7 halves
 constexpr int SB = 4 * PB;                       // bytes per ring slot: planes hi0, hi1 (shifted), lo0, lo1 (shifted)
 constexpr int SLOTS = 12, STAGE = 4;             // ring rows / rows per stage (SLOTS = STAGE + 8 halo rows)
 constexpr int RING = SLOTS * SB;                 // bytes per wave
-constexpr int PS = 64;                           // P plane stride (floats)
+constexpr int PS = 32 * SEG;                     // P plane stride (floats)
 constexpr int PW = 25 * PS;                      // floats per wave
 constexpr int NK = FU_NK;                        // layer-1 k-steps (80 taps in 5 x 16 slots; the 81st is an fp32 FMA)
 constexpr float F_INV = 1.f / 256.f;             // undoes FusedF16Weights' 2^8 weight scale (exact)
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     float* Pw = Pall + wv * PW;
     int pidx[5];                                                // P column read for dx = 0..4 (clamped to the image)
 #pragma unroll
-    for (int dx = 0; dx < 5; ++dx) pidx[dx] = clampi(clampi(cx0 + lane + dx - 2, 0, W - 1) - cx0, 0, 63);
+    for (int dx = 0; dx < 5; ++dx) pidx[dx] = clampi(clampi(cx0 + lane + dx - 2, 0, W - 1) - cx0, 0, 32 * SEG - 1);
     const int ox = cx0 + lane;                                  // output column of this lane
     const bool ox_ok = lane >= 2 && lane < 2 + OW && ox < W;
     // LDS byte address (inside a ring slot) of this lane's B fragment for segment 0: staged column q0, from the copy
@@ -251,23 +255,23 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     // into nine slices, one per layer-1 k-step, so every 12-MFMA k-step has ~64 VALU instructions to issue in its
     // shadow and the matrix pipe never waits for a conversion chain.  Accumulators ping-pong between two sets.
     // ---------------------------------------------------------------------------------------------------------------
-    f32x16 accA[2][2], accB[2][2];
-    auto step = [&](auto DO_L1, auto DO_L23, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], int a_nxt, int v_prev, int row_idx) {
+    f32x16 accA[SEG][2], accB[SEG][2];
+    auto step = [&](auto DO_L1, auto DO_L23, f32x16 (&cur)[SEG][2], f32x16 (&nxt)[SEG][2], int a_nxt, int v_prev, int row_idx) {
         constexpr bool L1 = decltype(DO_L1)::value, L23 = decltype(DO_L23)::value;
         if constexpr (DIAG) {
-            if (L1 && blockIdx.x == 0 && lane == 0 && row_idx < 64 && dbg) dbg[((size_t)wv * 64 + row_idx) * 4] = __builtin_amdgcn_s_memtime();
+            if (L1 && blockIdx.x == 0 && lane == 0 && row_idx < 64 && wv < 8 && dbg) dbg[((size_t)wv * 64 + row_idx) * 4] = __builtin_amdgcn_s_memtime();
         }
         int s0 = 0;
-        h8 bh[2], bl[2], a0h, a0l, a1h, a1l;
+        h8 bh[SEG], bl[SEG], a0h, a0l, a1h, a1l;
         auto wrap = [&](int r) { return s0 + r >= SLOTS ? s0 + r - SLOTS : s0 + r; };       // ring slot of window row r
-        auto load_step = [&](int s, h8 (&xbh)[2], h8 (&xbl)[2], h8& x0h, h8& x0l, h8& x1h, h8& x1l) {
+        auto load_step = [&](int s, h8 (&xbh)[SEG], h8 (&xbl)[SEG], h8& x0h, h8& x0l, h8& x1h, h8& x1l) {
             if (s < 4) {
                 // window rows 2s (lanes 0-31) and 2s+1 (lanes 32-63), taps dx = 0..7: 8 consecutive halves of one row
                 const unsigned off = (unsigned)((half ? wrap(2 * s + 1) : wrap(2 * s)) * SB);
                 const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + off));
                 const unsigned* yl = yh + 2 * PB / 4;
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < SEG; ++g) {
                     u32x4 hi4, lo4;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hi4[q] = yh[16 * g + q]; lo4[q] = yl[16 * g + q]; }
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                     const unsigned adr = frag_el + (unsigned)(half ? wrap(j) * SB + 16 : wrap(8) * SB + 2 * j);
                     const _Float16* e = reinterpret_cast<const _Float16*>(lds_raw + adr);
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) { xbh[g][j] = e[32 * g]; xbl[g][j] = e[32 * g + PB]; }
+                    for (int g = 0; g < SEG; ++g) { xbh[g][j] = e[32 * g]; xbl[g][j] = e[32 * g + PB]; }
                 }
             }
             x0h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 0) * 64 + lane) * 8);
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                 }
             }
         };
-        f32x16 c1b[2][2] = {}, c2b = {};                         // the C operands that open the chains (biases x 2^8 ...)
+        f32x16 c1b[SEG][2] = {}, c2b = {};                         // the C operands that open the chains (biases x 2^8 ...)
         h8 fa[2][2] = {};
         if constexpr (L1) {
             if (((a_nxt - A0) >> 2) > st_cur) {                 // the row opens the next ring stage (uniform branch)
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                 const f32x16 bias = *reinterpret_cast<const f32x16*>(B1s + half * 32 + 16 * blk);
                 const f32x16 w88 = *reinterpret_cast<const f32x16*>(W88s + half * 32 + 16 * blk);
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < SEG; ++g) {
                     const float y88 = (float)e88[32 * g] + (float)e88[32 * g + PB];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c1b[g][blk][r] = __builtin_fmaf(w88[r], y88, bias[r]);
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
         load_units(0, fa);
         __builtin_amdgcn_sched_barrier(0);
 
-        f32x16 acc2[2] = {}, accp[2] = {};
+        f32x16 acc2[SEG] = {}, accp[SEG] = {};
         auto run_unit = [&](Unit q, const h8 (&f)[2]) {
             float x[8];
             if (q.kind == 2) {
@@ -391,14 +395,14 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
         };
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            h8 nbh[2], nbl[2], n0h, n0l, n1h, n1l, fn[2][2] = {};
+            h8 nbh[SEG], nbl[SEG], n0h, n0l, n1h, n1l, fn[2][2] = {};
             if constexpr (L1) { if (s + 1 < NK) load_step(s + 1, nbh, nbl, n0h, n0l, n1h, n1l); }
             if (s + 1 < 9) load_units(s + 1, fn);
             __builtin_amdgcn_sched_barrier(0);                  // requests first: they may not sink towards their uses
             slice(s);
             if (L1 && s < NK) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < SEG; ++g) {
                     nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh[g], s == 0 ? c1b[g][0] : nxt[g][0], 0, 0, 0);
                     nxt[g][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh[g], s == 0 ? c1b[g][1] : nxt[g][1], 0, 0, 0);
                     nxt[g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl[g], nxt[g][0], 0, 0, 0);
@@ -419,7 +423,8 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
             __builtin_amdgcn_sched_barrier(0);                  // slices stay with their k-step
             if (s + 1 < 9) {
                 if (L1 && s + 1 < NK) {
-                    bh[0] = nbh[0]; bh[1] = nbh[1]; bl[0] = nbl[0]; bl[1] = nbl[1];
+#pragma unroll
+                    for (int g = 0; g < SEG; ++g) { bh[g] = nbh[g]; bl[g] = nbl[g]; }
                     a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
                 }
                 fa[0][0] = fn[0][0]; fa[0][1] = fn[0][1]; fa[1][0] = fn[1][0]; fa[1][1] = fn[1][1];
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     // Layers 2+3, the P hand-over and the gather of one row as ONE scheduling region (sequential form): all W2/W3
     // fragments are requested up front (both segments share them: 12 ds_read_b128), and the two segments' accumulator
     // chains are interleaved unit by unit, so one chain's conversions run in the shadow of the other chain's MFMAs.
-    auto l23 = [&](f32x16 (&cur)[2][2], int v_prev) {
+    auto l23 = [&](f32x16 (&cur)[SEG][2], int v_prev) {
         h8 w2h[2][2], w2l[2][2], w3h[2], w3l[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -444,13 +449,13 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
             w3l[ks] = *reinterpret_cast<const h8*>(W3f + ((ks * 2 + 1) * 64 + lane) * 8);
         }
         const f32x16 c2b = *reinterpret_cast<const f32x16*>(B2s + half * 16);
-        f32x16 acc2[2], accp[2] = {};
+        f32x16 acc2[SEG], accp[SEG] = {};
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < SEG; ++g) {
                     float x[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] = fmaxf(cur[g][blk][8 * ks + j] * F_INV, 0.f);
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < SEG; ++g) {
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = fmaxf(acc2[g][8 * ks + j] * F_INV, 0.f);
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
             }
         // P rows: register r of half h is tap 8*(r/4) + 4h + r%4; taps >= 25 are padding
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < SEG; ++g)
 #pragma unroll
             for (int r = 0; r < 13; ++r) {
                 const int t0 = 8 * (r >> 2) + (r & 3);
@@ -497,7 +502,8 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     using F = std::false_type;
     auto row_of = [&](int k) { return clampi(R0 - 2 + k, 0, H - 1); };    // the reference clamps layer-2 ACTIVATIONS at the border
 
-#if FU_SEQ
+#if FU_SEQ || FU_SEG != 2
+    static_assert(FU_SEQ, "the cross-row pipelined form (FU_SEQ=0) is written for two segments per wave");
     // sequential form (A/B experiment): layer 1 of a row, then its layers 2+3 -- no cross-row overlap, half the accumulators
 #pragma unroll 1
     for (int k = 0; k < nv; ++k) {
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
         step(T{}, F{}, accB, accA, row_of(k), 0, k);
         __builtin_amdgcn_s_setprio(FU_PRIO23);
         if constexpr (DIAG) {           // phase boundary stamp (after the last layer-1 MFMA has been issued)
-            if (blockIdx.x == 0 && lane == 0 && k < 64 && dbg) dbg[((size_t)wv * 64 + k) * 4 + 1] = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 0 && lane == 0 && k < 64 && wv < 8 && dbg) dbg[((size_t)wv * 64 + k) * 4 + 1] = __builtin_amdgcn_s_memtime();
         }
         l23(accA, R0 - 2 + k);
     }
@@ -544,7 +550,7 @@ void launch_fused_f16(const float* Y, int W, int H, int y_row_base, int y_rows, 
     if (out_rows <= 0) return;
     const int tiles_x = (W + GW - 1) / GW;
     // one workgroup per CU: cut the rows into just enough chunks to fill the chip (a chunk start costs 4 warm-up rows)
-    int chunks = std::max(1, (num_cus + tiles_x - 1) / tiles_x);
+    int chunks = std::max(1, num_cus / tiles_x);          // never more workgroups than CUs: one round, no tail
     chunks = std::min(chunks, std::max(1, out_rows / 16));
     const int chunk_rows = (out_rows + chunks - 1) / chunks;
     chunks = (out_rows + chunk_rows - 1) / chunk_rows;
