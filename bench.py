@@ -454,6 +454,17 @@ def main():
             out["roofline"]["kernel"] = {"fast": "k_conv12_mfma<fast> (fp32 MFMA FMA chains)", "fast_f16": "k_fused_f16 (all three layers, split-fp16 MFMA)"}[args.tier]
             out["roofline"]["note"] = "non-parity tier: priced with the same algorithmic FLOPs of layers 1+2 (+3 for the fused kernel: see whole_path)"
         if world == 1 and not args.no_extras and args.tier == "strict":
+            # SURVEY 8d also asks for the median of >= 10 device-timed steps: 10 more steps, each bracketed by HIP events on
+            # the launch stream (outside the contract's timed region, which may not contain extra synchronisation)
+            evs = [S.Event() for _ in range(11)]
+            evs[0].record()
+            for i in range(10):
+                step()
+                evs[i + 1].record()
+            S.sync()
+            per = sorted(evs[i].elapsed_ms(evs[i + 1]) for i in range(10))
+            out["device_ms_per_step"] = {"median": round((per[4] + per[5]) / 2, 4), "min": round(per[0], 4), "max": round(per[-1], 4),
+                                         "MPix/s_at_median": round(mpix_step / ((per[4] + per[5]) / 2 * 1e-3), 1), "steps": 10}
             # both generators: the headline above is `smooth`; `noise` is the worst case for rounding
             gens = {"smooth": round(value, 1)}
             load("noise")
