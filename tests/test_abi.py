@@ -74,6 +74,27 @@ def test_axis_table_matches_oracle(S, oracle_lib, dst, src, filt):
         assert np.array_equal(a[2][u, :n].view(np.uint64), b[2][u, :n].view(np.uint64)), u
 
 
+def test_axis_table_property_random_sizes(S, oracle_lib):
+    """Property test: for random (filter, destination length, source length) -- up-scales, down-scales, 1-pixel axes, prime
+    ratios -- the PRODUCT's host-side table builder (csrc/resample_table.hpp, through srcnn_axis_table: no device involved)
+    produces the oracle's bounds and weights bit for bit, and every range stays inside the source."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(filt=st.integers(0, 4), dst=st.integers(1, 700), src=st.integers(1, 700))
+    def check(filt, dst, src):
+        a = S.axis_table(dst, src, filt)
+        b = oracle_lib.axis_table(dst, src, filt)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[0].min() >= 0 and a[1].max() <= src - 1 and np.all(a[1] >= a[0])
+        n = a[1] - a[0] + 1
+        cols = np.arange(a[2].shape[1])[None, :]
+        used = cols < n[:, None]
+        assert np.array_equal(a[2].view(np.uint64)[used], b[2].view(np.uint64)[used])
+
+    check()
+
+
 def test_output_size_matches_reference_geometry(S, golden):
     """Geometry of the golden ProcessSRCNN outputs (incl. step scaling, made by the real reference)."""
     p = golden.process
