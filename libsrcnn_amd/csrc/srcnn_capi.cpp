@@ -1026,9 +1026,16 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
     const size_t in_b = in_n * sizeof(float), out_b = out_n * sizeof(float);
     const int mode = g.mode.load();
 
-    // page-lock the caller's frames so the copies are truly asynchronous; harmless if it fails
-    const bool reg_in = hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterDefault) == hipSuccess;
-    const bool reg_out = hipHostRegister(out, out_b * nframes, hipHostRegisterDefault) == hipSuccess;
+    // page-lock the caller's frames so the copies are truly asynchronous -- unless they already are (buffers from
+    // srcnn_host_alloc_pinned / hipHostMalloc: registering a gigabyte again costs milliseconds per call); harmless if it fails
+    auto pinned = [](const void* p) {
+        hipPointerAttribute_t a;
+        const bool yes = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        return yes;
+    };
+    const bool reg_in = !pinned(in) && hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterDefault) == hipSuccess;
+    const bool reg_out = !pinned(out) && hipHostRegister(out, out_b * nframes, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
 
     std::lock_guard<std::mutex> slk(g.stream_mu);
