@@ -26,6 +26,7 @@ C_ABI_SYMBOLS = [
     "srcnn_dev_alloc", "srcnn_dev_free", "srcnn_host_alloc_pinned", "srcnn_host_free_pinned",
     "srcnn_memcpy_h2d", "srcnn_memcpy_d2h", "srcnn_memset_dev", "srcnn_stream_create", "srcnn_stream_destroy",
     "srcnn_stream_sync", "srcnn_device_sync", "srcnn_event_create", "srcnn_event_destroy", "srcnn_event_record",
+    "srcnn_stream_wait_event",
     "srcnn_event_elapsed_ms",
     "srcnn_profile_enable", "srcnn_profile_reset", "srcnn_profile_read",
     "srcnn_y_upscale2x_f32_dev", "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev",
@@ -72,6 +73,7 @@ def lib():
             "srcnn_stream_sync": (i, [vp]), "srcnn_device_sync": (i, []),
             "srcnn_event_create": (i, [C.POINTER(vp)]), "srcnn_event_destroy": (i, [vp]),
             "srcnn_event_record": (i, [vp, vp]), "srcnn_event_elapsed_ms": (i, [vp, vp, C.POINTER(f)]),
+            "srcnn_stream_wait_event": (i, [vp, vp]),
             "srcnn_profile_enable": (i, [i]), "srcnn_profile_reset": (i, []),
             "srcnn_profile_read": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
             "srcnn_y_upscale2x_f32_dev": (i, [vp, u, u, vp, vp]),

@@ -109,7 +109,9 @@ struct Call {
 struct StageSpan { hipEvent_t a, b; int stage; };
 
 struct StreamSlot {         // one lane of the host-stream path; lives until srcnn_shutdown
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;          // kernels (slot 0's stream carries the kernels of BOTH slots, see the stream entry point)
+    hipStream_t cst = nullptr;         // this slot's copies, in both directions
+    hipEvent_t e_in = nullptr, e_k = nullptr, e_out = nullptr;   // frame landed / kernels done / result copied out
     float* din = nullptr;  size_t din_n = 0;
     float* dout = nullptr; size_t dout_n = 0;
     Workspace ws;                      // private: the captured graph has its pointers baked in
@@ -695,6 +697,9 @@ void srcnn_shutdown(void)
     for (auto& sl : g.slots) {
         if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
         if (sl.st) (void)hipStreamDestroy(sl.st);
+        if (sl.cst) (void)hipStreamDestroy(sl.cst);
+        for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        sl.cst = nullptr;
         (void)hipFree(sl.din); (void)hipFree(sl.dout);
         sl.ws.release();
         sl.tables.clear();
@@ -796,6 +801,7 @@ int srcnn_event_create(void** ev)
 }
 int srcnn_event_destroy(void* ev) { if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return SRCNN_OK; }
 int srcnn_event_record(void* ev, void* stream) { HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return SRCNN_OK; }
+int srcnn_stream_wait_event(void* stream, void* ev) { HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return SRCNN_OK; }
 int srcnn_event_elapsed_ms(void* start, void* stop, float* ms)
 {
     HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
@@ -1043,8 +1049,11 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
     for (int i = 0; i < nslots && !rc; ++i) {
         StreamSlot& sl = g.slots[i];
         if (!sl.st && hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
+        if (!rc && !sl.cst && hipStreamCreateWithFlags(&sl.cst, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
+        for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out})
+            if (!rc && !*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = fail(SRCNN_E_HIP, "event create");
         if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) {     // shape or mode changed: drop the graph first,
-            if (sl.exec) { (void)hipStreamSynchronize(sl.st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
+            if (sl.exec) { (void)hipStreamSynchronize(g.slots[0].st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
             sl.ws.frozen = false;                                          // then its buffers may move again
             sl.tables.clear();
             sl.gw = w; sl.gh = h; sl.gmode = mode; sl.uses = 0;
@@ -1052,37 +1061,80 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
         if (!rc) rc = grow(sl.din, sl.din_n, in_n);
         if (!rc) rc = grow(sl.dout, sl.dout_n, out_n);
     }
+    // Pipeline.  Copies run on the slots' copy-only streams and every copy/kernel dependency that involves a copy is
+    // resolved on the HOST: a copy that has to wait on another queue's event device-side does not overlap the other
+    // slot's kernels on this runtime (measured with tools/hs_probe.py, 4K frames: 12.2-12.4 ms per frame with the D2H on
+    // the kernel stream or behind hipStreamWaitEvent, 10.8 ms when the host waits for the kernels and then queues the
+    // copy on an idle stream).  So a copier thread waits for frame f's kernels and then issues its D2H; the main thread
+    // waits for the slot's previous D2H before it reuses the slot.
+    const int dev = g.device;
+    std::atomic<unsigned> launched{0};     // frames whose kernels have been queued (e_k recorded)
+    std::atomic<unsigned> copied{0};       // frames whose D2H has been queued (e_out recorded)
+    std::atomic<int> abort_copy{0}, copy_err{0};
+    std::thread copier([&] {
+        (void)hipSetDevice(dev);
+        for (unsigned f = 0; f < nframes; ++f) {
+            while (launched.load(std::memory_order_acquire) <= f) {
+                if (abort_copy.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            StreamSlot& sl = g.slots[f % nslots];
+            if (hipEventSynchronize(sl.e_k) != hipSuccess ||
+                hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.cst) != hipSuccess ||
+                hipEventRecord(sl.e_out, sl.cst) != hipSuccess) copy_err = 1;
+            copied.store(f + 1, std::memory_order_release);
+        }
+    });
+    hipStream_t ks = g.slots[0].st;        // ALL kernels go to one stream: frames back to back, never two frames' kernels
+                                           // sharing the chip (that costs more than it overlaps: the persistent layer-1+2
+                                           // kernel partitions its tiles over the workgroups it expects to be resident)
     for (unsigned f = 0; f < nframes && !rc; ++f) {
         StreamSlot& sl = g.slots[f % nslots];
         Call c;
-        c.s = sl.st; c.ws = &sl.ws; c.mode = mode; c.hold = &sl.tables;
-        if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "H2D"); break; }
+        c.s = ks; c.ws = &sl.ws; c.mode = mode; c.hold = &sl.tables;
+        if (f >= (unsigned)nslots) {
+            // the slot's previous frame: its kernels are done (the copier saw e_k) once its D2H has been queued; wait for
+            // that D2H to finish before din / dout are reused
+            while (copied.load(std::memory_order_acquire) < f - nslots + 1) std::this_thread::yield();
+            if (hipEventSynchronize(sl.e_out) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
+        }
+        // frame in: also resolved on the host (the previous frame's kernels keep the device busy meanwhile)
+        if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.cst) != hipSuccess ||
+            hipEventRecord(sl.e_in, sl.cst) != hipSuccess || hipEventSynchronize(sl.e_in) != hipSuccess) {
+            rc = fail(SRCNN_E_HIP, "H2D"); break;
+        }
         if (use_graph && sl.uses >= 1 && !sl.exec) {
             // The slot has run this shape eagerly once: tables and workspaces exist, so the kernel sequence
             // can be captured without any allocation inside the capture.
             hipGraph_t graph = nullptr;
             sl.ws.frozen = true;
             c.timing = false;              // event pairs cannot be timed inside a capture
-            if (hipStreamBeginCapture(sl.st, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
+            if (hipStreamBeginCapture(ks, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
             if (!rc) rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
-            if (hipStreamEndCapture(sl.st, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
+            if (hipStreamEndCapture(ks, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
             c.timing = true;
             if (!rc && hipGraphInstantiate(&sl.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(SRCNN_E_HIP, "graph instantiate");
             if (graph) (void)hipGraphDestroy(graph);
             if (rc) { sl.ws.frozen = false; break; }
         }
         if (use_graph && sl.exec) {
-            if (hipGraphLaunch(sl.exec, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
+            if (hipGraphLaunch(sl.exec, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
         } else {
             if (sl.tables.size() > 16) sl.tables.clear();   // eager runs re-take their references every frame
             rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
             if (rc) break;
         }
-        if (hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.st) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
+        if (hipEventRecord(sl.e_k, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "event record"); break; }
+        launched.store(f + 1, std::memory_order_release);
         ++sl.uses;
     }
-    for (int i = 0; i < nslots; ++i)
+    if (rc) abort_copy.store(1, std::memory_order_release);     // the copier stops at the first frame that was never launched
+    copier.join();
+    for (int i = 0; i < nslots; ++i) {
         if (g.slots[i].st) (void)hipStreamSynchronize(g.slots[i].st);
+        if (g.slots[i].cst) (void)hipStreamSynchronize(g.slots[i].cst);
+    }
+    if (!rc && copy_err) rc = fail(SRCNN_E_HIP, "a device-to-host copy of the frame stream failed");
     if (reg_in) (void)hipHostUnregister(const_cast<float*>(in));
     if (reg_out) (void)hipHostUnregister(out);
     return rc;
