@@ -1233,33 +1233,47 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
     const int dev = g.device;
     std::atomic<int> copy_err{0};
-    std::atomic<unsigned> enqueued{0};      // bands whose "landed" event has been recorded in THIS call
+    std::atomic<unsigned> enqueued{0};      // bands whose kernels have been queued (their "computed" event recorded) in THIS call
+    std::atomic<int> abort_bands{0};
+    // The helper resolves the copy dependencies on the HOST: it waits for a band's kernels, then queues the band's D2H on
+    // the idle copy stream (a copy that waits device-side on the kernel stream's event does not run beside the next band's
+    // kernels on this runtime, profiles/r02_stream_overlap.txt), and fans the previous band out to the caller's buffers
+    // while that copy is in flight.
     std::thread fanout([&] {
         (void)hipSetDevice(dev);
-        for (unsigned b = 0; b < nb; ++b) {
-            while (enqueued.load(std::memory_order_acquire) <= b) std::this_thread::yield();
+        auto fan = [&](unsigned b) {
             if (hipEventSynchronize(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
             const size_t p0 = (size_t)r0s[b] * dw, p1 = (size_t)r0s[b + 1] * dw;
             parallel_memcpy(out + p0 * d, pin_rgb + p0 * d, (p1 - p0) * d);
             if (conv_opt) parallel_memcpy(conv_opt + p0, pin_conv + p0, p1 - p0);
+        };
+        unsigned done = 0;
+        for (unsigned b = 0; b < nb; ++b) {
+            while (enqueued.load(std::memory_order_acquire) <= b) {
+                if (abort_bands.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            const size_t p0 = (size_t)r0s[b] * dw, pn = (size_t)(r0s[b + 1] - r0s[b]) * dw;
+            if (hipEventSynchronize(L.band_events[2 * b]) != hipSuccess ||
+                hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
+                (conv_opt && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess) ||
+                hipEventRecord(L.band_events[2 * b + 1], L.copy_st) != hipSuccess) { copy_err = 1; return; }
+            if (b > 0) fan(b - 1);
+            done = b;
         }
+        fan(done);
     });
     int launch_rc = SRCNN_OK;
     for (unsigned b = 0; b < nb; ++b) {
         const unsigned r0 = r0s[b], r1 = r0s[b + 1];
         const size_t p0 = (size_t)r0 * dw, pn = (size_t)(r1 - r0) * dw;
-        if (!launch_rc) launch_rc = y_path_rows(c, sp[0], w, h, dw, dh, filter, r0, r1, dp[0] + p0);
+        launch_rc = y_path_rows(c, sp[0], w, h, dw, dh, filter, r0, r1, dp[0] + p0);
         if (!launch_rc) {
             launch_ycc_merge(dp[0] + p0, dp[1] + p0, dp[2] + p0, dp[3] + p0, pn, (int)d, d_out + p0 * d,
                              conv_opt ? d_conv + p0 : nullptr, s);
-            if (hipEventRecord(L.band_events[2 * b], s) != hipSuccess ||
-                hipStreamWaitEvent(L.copy_st, L.band_events[2 * b], 0) != hipSuccess ||
-                hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
-                (conv_opt && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess))
-                launch_rc = fail(SRCNN_E_HIP, "band %u copy enqueue failed", b);
+            if (hipEventRecord(L.band_events[2 * b], s) != hipSuccess) launch_rc = fail(SRCNN_E_HIP, "band %u event record failed", b);
         }
-        // the fan-out thread waits on this event for every band, so it is recorded even after a failure
-        (void)hipEventRecord(L.band_events[2 * b + 1], L.copy_st);
+        if (launch_rc) { abort_bands.store(1, std::memory_order_release); break; }
         enqueued.store(b + 1, std::memory_order_release);
     }
     fanout.join();
