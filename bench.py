@@ -151,18 +151,22 @@ def process_srcnn_wall(S):
     out = {}
     for name, (h, w) in (("1920x1080_rgb", (1080, 1920)), ("3840x2160_rgb", (2160, 3840))):
         img = synth_rgb(h, w, 0x5C0DE000 + h)
-        ts = []
+        ts, cs = [], []
         for it in range(6):
             o, osz = C.c_void_p(), C.c_uint(0)
+            c0 = time.process_time()
             t0 = time.perf_counter()
             rc = fn(img.ctypes.data, w, h, 3, 2.0, C.byref(o), C.byref(osz), None, None)
             dt = time.perf_counter() - t0
+            dc = time.process_time() - c0
             assert rc == 0 and osz.value == 4 * h * w * 3, (rc, osz.value)
             L.srcnn_delete_array(o)
             if it:
                 ts.append(dt)
+                cs.append(dc)
         out[name] = {"best_ms": round(min(ts) * 1e3, 2), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 2),
-                     "MPix/s": round(4 * h * w / 1e6 / min(ts), 1)}
+                     "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
+                     "host_cpu_ms_per_call": round(sorted(cs)[len(cs) // 2] * 1e3, 2)}
     out["note"] = "host u8 RGB in -> host u8 RGB out through the drop-in symbol; includes H2D, colour split, chroma " \
                   "resample, Y path, merge, D2H and the new[] of the result"
     return out
@@ -170,44 +174,197 @@ def process_srcnn_wall(S):
 
 def pcie_inclusive(S, frames=8):
     """Stream of host-resident (page-locked) 4K Y frames: H2D + path + D2H per frame, two slots, hipGraph per slot."""
-    import ctypes as C
-    L = S.lib()
+    step, free = host_stream_setup(S, frames)
     w, h, F = IN_W, IN_H, frames
-    pin_in = L.srcnn_host_alloc_pinned(F * w * h * 4)
-    pin_out = L.srcnn_host_alloc_pinned(F * 4 * w * h * 4)
-    fr = np.ctypeslib.as_array(C.cast(pin_in, C.POINTER(C.c_float)), (F, h, w))
-    out = np.ctypeslib.as_array(C.cast(pin_out, C.POINTER(C.c_float)), (F, 2 * h, 2 * w))
-    from libsrcnn_amd import synth
-    two = synth.frames(2, h, w, 0, "smooth")
-    for f in range(F):
-        fr[f] = two[f & 1]
-    S.check(L.srcnn_y_upscale2x_f32_stream(fr.ctypes.data, w, h, F, out.ctypes.data, 1))     # warm-up + capture
-    ts = []
+    step()                                                       # warm-up + capture
+    ts, cs = [], []
     for _ in range(3):
+        c0 = time.process_time()
         t0 = time.perf_counter()
-        S.check(L.srcnn_y_upscale2x_f32_stream(fr.ctypes.data, w, h, F, out.ctypes.data, 1))
+        step()
         ts.append(time.perf_counter() - t0)
-    L.srcnn_host_free_pinned(pin_in); L.srcnn_host_free_pinned(pin_out)
+        cs.append(time.process_time() - c0)
+    free()
     return {"value": round(F * 4 * w * h / 1e6 / min(ts), 1), "unit": "MPix/s", "frames": F, "best_of": 3,
             "bytes_per_output_px": {"h2d": 1.0, "d2h": 4.0},
+            "host_cpu_s_per_frame": round(min(cs) / F, 6), "wall_s_per_frame": round(min(ts) / F, 6),
             "note": "planar f32 Y frames in page-locked host memory, H2D + path + D2H overlapped over two slots "
-                    "(srcnn_y_upscale2x_f32_stream, hipGraph per slot); never the headline value"}
+                    "(srcnn_y_upscale2x_f32_stream, hipGraph per slot); host_cpu_s_per_frame = process CPU time (all "
+                    "threads) per frame: the helper threads block, they do not spin; never the headline value"}
 
 
-def side_workload(args):
-    """The other BASELINE.json configurations.  Same timing protocol; reported with the same keys but they are
-    NOT the headline line the driver records (that is --workload frames)."""
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes ourselves.
+
+    The parent NEVER touches the GPU (it does not even load libsrcnn_amd.so): every rank is a fresh child created
+    with subprocess -- no exec from a process that has initialised HIP -- with the RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* environment torch.distributed.run would have given it.  Rank 0's stdout carries the single JSON line,
+    which the parent relays; the other ranks' stdout goes to stderr.  Exit code = first failing rank's, and a
+    failed rank takes the others down (by PID) instead of leaving them blocked in a barrier."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    rc = 0
+    out0 = ""
+    try:
+        pending = set(range(n))
+        import threading
+        box = {}
+        t0 = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+        t0.start()
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                    for o in pending:
+                        procs[o].terminate()
+            time.sleep(0.05)
+        t0.join(timeout=10)
+        out0 = box.get("out", "") or ""
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    for ln in out0.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 3
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+    return rc
+
+
+def rendezvous(args):
+    """RANK / LOCAL_RANK / WORLD_SIZE from the environment (torch.distributed.run or launch_ranks) and, for N > 1, a
+    gloo process group: CPU-side only (barriers, max of a scalar, the RCCL id).  The data path of the headline
+    workload has no collective, and each process drives its GPU through libsrcnn_amd.so's own HIP runtime."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        args.gpus = world
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, local_rank, world, dist
+
+
+def reduce_max(dist, x):
+    if dist is None:
+        return x
+    import torch
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def reduce_min(dist, x):
+    return -reduce_max(dist, -x)
+
+
+def rccl_probe(S, dist, rank, world, ndev, timeout_s=120.0):
+    """Outside the timed region: create the RCCL communicator inside libsrcnn_amd.so across all ranks and run ONE
+    srcnn_comm_barrier, so the line can say how many ranks RCCL actually connected (`rccl_ranks`).  The id travels
+    over gloo in the main thread; init + barrier run in a helper thread with a deadline so that a wedged fabric
+    costs the line its `rccl_ranks`, never the measurement (the headline data path has no collective).
+    Returns (nranks or None, note or None)."""
+    import ctypes as C
+    import threading
+    L = S.lib()
+    if world > ndev:
+        return None, "%d ranks alias %d device(s): RCCL refuses two ranks on one device, so no communicator was made" % (world, ndev)
+    ident = (C.c_ubyte * 128)()
+    ok = 1.0
+    if rank == 0:
+        ok = 1.0 if L.srcnn_comm_unique_id(ident) == 0 else 0.0
+    if dist is not None:
+        box = [bytes(ident) if ok else None]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            return None, "srcnn_comm_unique_id failed on rank 0"
+        ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    elif not ok:
+        return None, "srcnn_comm_unique_id failed: " + L.srcnn_last_error().decode()
+    res = {}
+
+    def work():
+        try:
+            S.check(L.srcnn_comm_init(ident, rank, world))
+            S.check(L.srcnn_comm_barrier(None))
+            r, n = C.c_int(-1), C.c_int(-1)
+            S.check(L.srcnn_comm_rank(C.byref(r), C.byref(n)))
+            res["n"] = n.value
+        except Exception as e:                                   # noqa: BLE001
+            res["err"] = repr(e)
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    mine = float(res.get("n", 0))
+    agreed = reduce_min(dist, mine)                              # every rank must have seen the same communicator
+    if th.is_alive():
+        return None, "RCCL init/barrier did not finish within %.0f s on rank %d" % (timeout_s, rank)
+    if agreed != world:
+        return None, res.get("err", "RCCL connected %d of %d ranks" % (int(agreed), world))
+    return int(agreed), None
+
+
+def host_stream_setup(S, frames):
+    """Page-locked 4K frames for the PCIe-inclusive stream (BASELINE config #5): returns (step, free)."""
+    import ctypes as C
+    from libsrcnn_amd import synth
+    L = S.lib()
+    w, h, F = IN_W, IN_H, frames
+    pin_in = L.srcnn_host_alloc_pinned(F * w * h * 4)
+    pin_out = L.srcnn_host_alloc_pinned(F * 4 * w * h * 4)
+    if not pin_in or not pin_out:
+        raise RuntimeError("pinned allocation failed: " + L.srcnn_last_error().decode())
+    fr = np.ctypeslib.as_array(C.cast(pin_in, C.POINTER(C.c_float)), (F, h, w))
+    two = synth.frames(2, h, w, 0, "smooth")
+    for f in range(F):
+        fr[f] = two[f & 1]
+
+    def step():
+        S.check(L.srcnn_y_upscale2x_f32_stream(pin_in, w, h, F, pin_out, 1))
+
+    def free():
+        L.srcnn_host_free_pinned(pin_in); L.srcnn_host_free_pinned(pin_out)
+    return step, free
+
+
+def side_workload(args):
+    """The other BASELINE.json configurations.  Same timing protocol (barrier + device sync on both sides of the timed
+    steps, max over ranks, whole-job aggregate); reported with the same keys but they are NOT the headline line the
+    driver records (that is --workload frames)."""
+    rank, local_rank, world, dist = rendezvous(args)
+    if args.dry_run:
+        return dry_run_line(args, rank, world, dist)
     import libsrcnn_amd as S
     from libsrcnn_amd import synth, multigpu
-    S.init(local_rank % max(1, S.device_count()))
+    ndev = max(1, S.device_count())
+    S.init(local_rank % ndev)
     L = S.lib()
     extra = {}
 
@@ -216,13 +373,17 @@ def side_workload(args):
             dist.barrier()
 
     verify = None
+    cleanup = None
+    cpu0 = None
     if args.workload == "tiled8k":
         import hashlib
         w, h = args.tiled_size
         y = synth.plane(h, w, synth.SEED0, "smooth")          # every rank can generate the frame (counter-based)
         d_in = S.DeviceBuffer.from_numpy(y)
         multigpu.init_comm_from_torch_dist(dist, rank, world)
-        tiled = multigpu.TiledFrameGPU(w, h, rank, world)
+        tiled = multigpu.TiledFrameGPU(w, h, rank, world, nsub=args.sub_bands)
+        extra["rccl_ranks"] = world
+        extra["sub_bands"] = tiled.nsub
 
         def step():
             tiled.step(d_in)
@@ -239,12 +400,15 @@ def side_workload(args):
             assert got == want, "gathered frame differs from the whole-frame result"
             return {"gathered_sha256": got, "equals_whole_frame_call": True}
         mpix_step = 4 * w * h / 1e6
-        label = "one %dx%d Y frame -> %dx%d, %d output bands + RCCL gatherv to rank 0" % (w, h, 2 * w, 2 * h, world)
+        label = "one %dx%d Y frame -> %dx%d, %d output bands (each in %d sub-bands, gather of sub-band k overlapped with " \
+                "the kernels of k+1) + RCCL gatherv to rank 0" % (w, h, 2 * w, 2 * h, world, tiled.nsub)
     elif args.workload == "host-stream":
-        r = pcie_inclusive(S, max(args.frames, 8))
-        if rank == 0:
-            print(json.dumps({"metric": METRIC + " incl. PCIe", **r}), flush=True)
-        return
+        F = max(args.frames, 8)
+        step, cleanup = host_stream_setup(S, F)
+        mpix_step = world * F * 4 * IN_W * IN_H / 1e6
+        label = "stream of %d host-resident (page-locked) 3840x2160 Y frames per rank per step: H2D + path + D2H over two " \
+                "slots, one hipGraph per slot (BASELINE config #5 shape), frames sharded %d-way" % (F, world)
+        extra["bytes_per_output_px_over_pcie"] = {"h2d": 1.0, "d2h": 4.0}
     elif args.workload == "frames-graph":
         import ctypes as C
         w, h, F = IN_W, IN_H, args.frames
@@ -272,32 +436,62 @@ def side_workload(args):
         mpix_step = world * F * 4 * w * h / 1e6
         label = "batch of 64 resident 1920x1080 frames per rank per step"
 
+    if args.workload != "tiled8k" and world > 1:
+        extra["rccl_ranks"], note = rccl_probe(S, dist, rank, world, ndev)
+        if note:
+            extra["rccl_note"] = note
+
     for _ in range(args.warmup):
         step()
     S.sync(); barrier()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     S.sync(); barrier()
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
-    if dist is not None:
-        import torch
-        t = torch.tensor([ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t[0])
+    cpu_s = (time.process_time() - cpu0) / args.steps
+    ms = reduce_max(dist, ms)
+    cpu_s = reduce_max(dist, cpu_s)
     if verify is not None:
         extra["verify"] = verify()
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": round(mpix_step / (ms * 1e-3), 2),
+        print(json.dumps({"metric": METRIC + (" incl. PCIe" if args.workload == "host-stream" else ""),
+                          "value": round(mpix_step / (ms * 1e-3), 2),
                           "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(ms, 4), "higher_is_better": True,
                           "scaling": "strong" if args.workload == "tiled8k" else "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "config": {"workload": label, "mode": "strict"}, **extra}), flush=True)
+                          "data": "synthetic", "config": {"workload": label, "mode": "strict"},
+                          "host_cpu_s_per_step_max_rank": round(cpu_s, 5), **extra}), flush=True)
     barrier()
-    if args.workload == "tiled8k":
-        L.srcnn_comm_destroy()
+    if cleanup is not None:
+        cleanup()
+    L.srcnn_comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dry_run_line(args, rank, world, dist):
+    """--dry-run: the launcher / rendezvous / aggregation plumbing with NO device and no library load (CPU test of
+    `bench.py --gpus N`).  `value` is null: nothing was measured."""
+    import socket
+    seen = [None] * world
+    if dist is not None:
+        dist.all_gather_object(seen, (rank, os.getpid()))
+        dist.barrier()
+    else:
+        seen = [(rank, os.getpid())]
+    t = reduce_max(dist, float(rank + 1))
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "MPix/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "ranks_seen": [r for r, _ in seen],
+                          "distinct_pids": len({p for _, p in seen}), "max_over_ranks_check": t,
+                          "parent_pid": os.getppid(), "host": socket.gethostname(),
+                          "config": {"workload": args.workload}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def traffic_record():
@@ -334,26 +528,20 @@ def main():
                          "host-stream: PCIe-inclusive stream of 4K frames from host memory (hipGraph per slot); "
                          "batch1080p: 64 resident 1920x1080 frames per step; "
                          "frames-graph: the headline workload replayed from one captured hipGraph per step")
+    ap.add_argument("--sub-bands", type=int, default=4, help="tiled8k: sub-bands per rank (gather of k overlaps compute of k+1)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher/rendezvous plumbing only: no device, value = null")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become the launcher.  Nothing in this process has touched (or will touch) the GPU.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("SRCNN_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and args.dry_run:
+        sys.exit(7)                        # test hook (tests/test_bench_launcher.py): a rank that dies before the rendezvous
     if args.workload != "frames":
         return side_workload(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
-
-    dist = None
-    if world > 1:
-        # CPU-side rendezvous only (barrier + max of a scalar).  The data path has no collective, and this
-        # process drives its GPU through libsrcnn_amd.so's own HIP runtime, so torch never touches the device.
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rank, local_rank, world, dist = rendezvous(args)
+    if args.dry_run:
+        return dry_run_line(args, rank, world, dist)
 
     def barrier():
         if dist is not None:
@@ -388,6 +576,12 @@ def main():
         S.sync()
         return (time.perf_counter() - t0) / k
 
+    # N > 1: prove, outside the timed region, that RCCL connects all N ranks (one communicator + one barrier); the
+    # headline data path itself has no collective
+    rccl_ranks, rccl_note = (None, None)
+    if world > 1:
+        rccl_ranks, rccl_note = rccl_probe(S, dist, rank, world, ndev)
+
     for _ in range(args.warmup):
         step()
     S.sync()
@@ -405,12 +599,7 @@ def main():
     S.profile_enable(False)
     prof = S.profile_read()
 
-    ms_per_step = (t1 - t0) * 1e3 / args.steps
-    if dist is not None:
-        import torch
-        t = torch.tensor([ms_per_step], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms_per_step = float(t[0])
+    ms_per_step = reduce_max(dist, (t1 - t0) * 1e3 / args.steps)
 
     if rank == 0:
         mpix_step = world * F * n_out / 1e6
@@ -450,7 +639,13 @@ def main():
             "max_abs_dY_vs_cpu_ref": None,
             "device": S.device_name(),
         }
+        if world > 1:
+            out["rccl_ranks"] = rccl_ranks
+            out["devices_visible"] = ndev
+            if rccl_note:
+                out["rccl_note"] = rccl_note
         if args.tier != "strict":
+            out["metric"] = METRIC + " [NON-PARITY tier %s]" % args.tier
             out["roofline"]["kernel"] = {"fast": "k_conv12_mfma<fast> (fp32 MFMA FMA chains)", "fast_f16": "k_fused_f16 (all three layers, split-fp16 MFMA)"}[args.tier]
             out["roofline"]["note"] = "non-parity tier: priced with the same algorithmic FLOPs of layers 1+2 (+3 for the fused kernel: see whole_path)"
         if world == 1 and not args.no_extras and args.tier == "strict":

@@ -35,7 +35,8 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define SRCNN_AMD_ABI_VERSION 2   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts */
+#define SRCNN_AMD_ABI_VERSION 3   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts
+                                   * 3: contexts (srcnn_init_devices ...), node-level calls, srcnn_trim, sub-band gather */
 
 /* error codes.  -1/-2/-11/-12/-100 are the reference's own (src/libsrcnn.cpp:951-966,883,910,636) */
 #define SRCNN_OK            0
@@ -74,18 +75,38 @@ extern "C" {
  *     serialised while they enqueue, different streams are independent.
  *   - The numerics mode is sampled once when a call starts; srcnn_set_mode never affects a call in flight.
  *   - srcnn_stream_destroy / srcnn_batch_graph_destroy / srcnn_shutdown must not race with calls that still use
- *     that stream / graph / the library (as with any handle). ---- */
+ *     that stream / graph / the library (as with any handle).
+ *
+ * Contexts (one process, several GPUs).  A context is one device binding with everything that lives in that device's
+ * memory (weights, table cache, workspaces, lanes).  srcnn_init(device) creates context 0 -- the one-device-per-process
+ * model of `torchrun`-style launches.  srcnn_init_devices(list, n) creates n contexts, list[k] = HIP device of context k
+ * (NULL / n <= 0: one context per visible device; a device may be listed more than once -- "virtual contexts", used to
+ * test the node-level paths on a one-GPU machine).  A process that never calls either self-initialises from the
+ * environment: SRCNN_DEVICES=all | <comma list of device ids>, default device 0.
+ *   - With more than one context, the calls that take HOST memory use the whole node on their own: srcnn_process_u8 /
+ *     ProcessSRCNN deal the bands of a large image to the contexts (the reference's one call saturates its machine through
+ *     OpenMP, src/libsrcnn.cpp:665,791-798,817-824), srcnn_y_upscale2x_f32_stream deals the frames.
+ *   - Calls that take DEVICE pointers run on the context that owns the given stream (srcnn_stream_create remembers it),
+ *     or, for the NULL stream, on the calling thread's current context: srcnn_set_context(k), default 0 (thread-local,
+ *     like hipSetDevice).  Allocation / event / sync plumbing also follows the current context. ---- */
 int         srcnn_abi_version(void);
 int         srcnn_device_count(void);              /* number of visible HIP devices (0 if none) */
-int         srcnn_init(int device);                /* bind this process to `device`, upload weights */
-void        srcnn_shutdown(void);                  /* free workspaces, streams, comm */
+int         srcnn_init(int device);                /* bind context 0 to `device` (< 0: SRCNN_DEVICES or device 0), upload weights */
+int         srcnn_init_devices(const int* devices, int n);   /* one context per entry; NULL / n <= 0: every visible device */
+int         srcnn_context_count(void);
+int         srcnn_context_device(int k);           /* HIP device of context k, or < 0 */
+int         srcnn_set_context(int k);              /* current context of the calling thread; returns the previous one or < 0 */
+int         srcnn_get_context(void);
+void        srcnn_shutdown(void);                  /* free workspaces, streams, comm, all contexts */
+int         srcnn_trim(void);                      /* give back what idle lanes and unreferenced cache entries hold */
 const char* srcnn_last_error(void);
 int         srcnn_set_mode(int mode);              /* SRCNN_MODE_*; returns previous mode or <0 */
 int         srcnn_get_mode(void);
 int         srcnn_device_name(char* buf, size_t cap);
 /* Upper bound, in bytes, on the layer-2 scratch (128 B per output pixel) one pass may hold; larger frames / bands
  * are produced in horizontal sub-bands with identical results.  Default 16 GiB or env SRCNN_MAX_WORKSPACE_MB.
- * Returns the previous limit.  Applies to calls that start afterwards. */
+ * Returns the previous limit.  Applies to calls that start afterwards, including the bands of srcnn_process_u8.  A band is
+ * never smaller than 16 rows (one tile row of the layer kernels), so a limit below 16 rows' worth is exceeded, not refused. */
 size_t      srcnn_set_workspace_limit(size_t bytes);
 
 /* ---- device memory / stream / event plumbing so callers need no HIP headers ---- */
@@ -144,6 +165,14 @@ int srcnn_batch_graph_destroy(void* graph);
  * d_out_band receives rows*2w floats.  Bit-identical to the same rows of the whole-frame call. */
 int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h,
                                    unsigned row0, unsigned rows, float* d_out_band, void* stream);
+
+/* ONE device-resident frame tiled over ALL contexts of this process (BASELINE config "single 8K frame tiled across 8
+ * MI355X", from one process): d_in (w*h) and d_out (2w*2h) live on the calling thread's current context (the root).  Every
+ * context pulls the source rows its output band needs from the root device, computes the band in `sub_bands` pieces
+ * (<= 0: 4) and pushes each finished piece to d_out on the root with hipMemcpyPeerAsync while the next piece computes
+ * (the push of sub-band k overlaps the kernels of k+1; one xGMI link per peer).  Synchronous: d_out is complete on return.
+ * Bit-identical to srcnn_y_upscale2x_f32_dev.  The multi-PROCESS counterpart is srcnn_comm_tiled_y_upscale2x_f32_dev. */
+int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, float* d_out, int sub_bands);
 
 /* General Y path: resample to (dw,dh) with any SRCNNFilterType, then the three convolutions
  * (what doSRCNN does for non-2x factors / other filters; src/libsrcnn.cpp:662-723). */
@@ -215,10 +244,11 @@ int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, 
 int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, unsigned long long* d_dbg, void* stream);
 
 /* Test hook: number of contribution tables currently cached (bounded, only unreferenced tables are evicted) and
- * of ProcessSRCNN lanes created so far (at most 4). */
+ * of ProcessSRCNN lanes created so far (at most 4 per context), both summed over the contexts. */
 int srcnn_debug_counts(int* tables, int* lanes);
 
-/* ---- multi-GPU: one process per GPU, RCCL over xGMI only for the final band gather ----
+/* ---- multi-GPU, one process per GPU: RCCL over xGMI only for the band gather.  The communicator binds to the calling
+ * thread's current context (its device).
  * The unique id is produced on rank 0 and handed to the other ranks by the caller's own
  * bootstrap (torch.distributed/gloo store, MPI, a file ...). */
 #define SRCNN_COMM_ID_BYTES 128
@@ -233,6 +263,22 @@ int srcnn_comm_gather_f32(const float* d_send, size_t count, float* d_recv, int 
  * d_recv + counts[0] + ... + counts[r-1] on the root, so bands of unequal height -- an output height the rank
  * count does not divide -- assemble into one contiguous frame.  A count may be 0. */
 int srcnn_comm_gatherv_f32(const float* d_send, const size_t* counts, float* d_recv, int root, void* stream);
+/* The same with explicit destinations: rank r's counts[r] floats land at d_recv + offsets[r] on the root (counts and
+ * offsets identical on every rank).  This is what lets a band be gathered piece by piece while it is being computed. */
+int srcnn_comm_gatherv_at_f32(const float* d_send, const size_t* counts, const size_t* offsets, float* d_recv, int root,
+                              void* stream);
+/* ONE frame tiled over the ranks of the communicator, compute and gather overlapped (BASELINE config "single 8K frame tiled
+ * across 8 MI355X ... RCCL gather over xGMI"): this rank's band of the 2h output rows (rows split as evenly as possible,
+ * earlier ranks take the remainder) is computed in `sub_bands` pieces (<= 0: 4) on `stream`; as soon as piece k's kernels
+ * are queued, its gather (peer->root ncclSend/ncclRecv, one group) is queued on the library's comm stream behind an event,
+ * so it runs while piece k+1 computes.  d_in: the whole w*h source frame on every rank; d_band: scratch for this rank's
+ * band (rows*2w floats); d_full: the 2w*2h result on the root (ignored elsewhere).  On return everything is queued and
+ * `stream` has been made to wait for the last gather: synchronise `stream` to use d_full.  Every rank must call it with the
+ * same w, h, root and sub_bands.  Bit-identical to srcnn_y_upscale2x_f32_dev on the root. */
+int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_band, float* d_full, int root,
+                                         int sub_bands, void* stream);
+/* rows [*row0, *row0 + *rows) of the out_h output rows that `rank` of `nranks` owns in the tiled path above */
+int srcnn_band_rows(unsigned out_h, int rank, int nranks, unsigned* row0, unsigned* rows);
 int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, void* stream);
 int srcnn_comm_barrier(void* stream);
 

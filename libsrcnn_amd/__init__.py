@@ -21,7 +21,8 @@ MODE_STRICT, MODE_FAST, MODE_FAST_F16 = 0, 1, 2
 
 # every symbol include/srcnn_amd.h declares (checked by tests/test_abi.py)
 C_ABI_SYMBOLS = [
-    "srcnn_abi_version", "srcnn_device_count", "srcnn_init", "srcnn_shutdown", "srcnn_last_error",
+    "srcnn_abi_version", "srcnn_device_count", "srcnn_init", "srcnn_init_devices", "srcnn_context_count",
+    "srcnn_context_device", "srcnn_set_context", "srcnn_get_context", "srcnn_shutdown", "srcnn_trim", "srcnn_last_error",
     "srcnn_set_mode", "srcnn_get_mode", "srcnn_device_name", "srcnn_set_workspace_limit",
     "srcnn_dev_alloc", "srcnn_dev_free", "srcnn_host_alloc_pinned", "srcnn_host_free_pinned",
     "srcnn_memcpy_h2d", "srcnn_memcpy_d2h", "srcnn_memset_dev", "srcnn_stream_create", "srcnn_stream_destroy",
@@ -30,6 +31,7 @@ C_ABI_SYMBOLS = [
     "srcnn_event_elapsed_ms",
     "srcnn_profile_enable", "srcnn_profile_reset", "srcnn_profile_read",
     "srcnn_y_upscale2x_f32_dev", "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev",
+    "srcnn_y_upscale2x_f32_node_dev",
     "srcnn_batch_graph_create", "srcnn_batch_graph_launch", "srcnn_batch_graph_destroy",
     "srcnn_y_path_f32_dev", "srcnn_resample_f32_dev", "srcnn_conv1_f32_dev", "srcnn_conv2_f32_dev",
     "srcnn_conv3_f32_dev", "srcnn_conv12_f32_dev",
@@ -37,7 +39,8 @@ C_ABI_SYMBOLS = [
     "srcnn_process_u8",
     "srcnn_delete_array", "srcnn_output_size", "srcnn_axis_table",
     "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_rank", "srcnn_comm_gather_f32",
-    "srcnn_comm_gatherv_f32", "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_debug_counts", "srcnn_fused_diag",
+    "srcnn_comm_gatherv_f32", "srcnn_comm_gatherv_at_f32", "srcnn_comm_tiled_y_upscale2x_f32_dev", "srcnn_band_rows",
+    "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_debug_counts", "srcnn_fused_diag",
 ]
 CXX_SYMBOLS = ["_Z20ConfigureFilterSRCNN15SRCNNFilterTypeb", "_Z12ProcessSRCNNPKhjjjfRPhRjPS1_Pj"]
 
@@ -62,6 +65,12 @@ def lib():
         vp, u, f, sz, i = C.c_void_p, C.c_uint, C.c_float, C.c_size_t, C.c_int
         sig = {
             "srcnn_abi_version": (i, []), "srcnn_device_count": (i, []), "srcnn_init": (i, [i]),
+            "srcnn_init_devices": (i, [C.POINTER(i), i]), "srcnn_context_count": (i, []), "srcnn_context_device": (i, [i]),
+            "srcnn_set_context": (i, [i]), "srcnn_get_context": (i, []), "srcnn_trim": (i, []),
+            "srcnn_y_upscale2x_f32_node_dev": (i, [vp, u, u, vp, i]),
+            "srcnn_comm_gatherv_at_f32": (i, [vp, C.POINTER(sz), C.POINTER(sz), vp, i, vp]),
+            "srcnn_comm_tiled_y_upscale2x_f32_dev": (i, [vp, u, u, vp, vp, i, i, vp]),
+            "srcnn_band_rows": (i, [u, i, i, C.POINTER(u), C.POINTER(u)]),
             "srcnn_shutdown": (None, []), "srcnn_last_error": (C.c_char_p, []), "srcnn_set_mode": (i, [i]),
             "srcnn_get_mode": (i, []), "srcnn_device_name": (i, [C.c_char_p, sz]),
             "srcnn_set_workspace_limit": (sz, [sz]),
@@ -120,6 +129,31 @@ def check(rc):
 
 def init(device=0):
     check(lib().srcnn_init(int(device)))
+
+
+def init_devices(devices=None):
+    """One context per entry of `devices` (HIP device ids; an id may repeat = virtual contexts); None = every visible device."""
+    if devices is None:
+        check(lib().srcnn_init_devices(None, 0))
+    else:
+        arr = (C.c_int * len(devices))(*devices)
+        check(lib().srcnn_init_devices(arr, len(devices)))
+    return lib().srcnn_context_count()
+
+
+def context_count():
+    return lib().srcnn_context_count()
+
+
+def set_context(k):
+    prev = lib().srcnn_set_context(int(k))
+    if prev < 0:
+        raise SrcnnError(prev, lib().srcnn_last_error().decode())
+    return prev
+
+
+def shutdown():
+    lib().srcnn_shutdown()
 
 
 def device_count():

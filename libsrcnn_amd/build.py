@@ -12,8 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrcnn_amd.so")
 
-SOURCES = ["srcnn_kernels.hip", "srcnn_fused_f16.hip", "srcnn_capi.cpp", "srcnn_comm.cpp", "dropin.cpp"]
-DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "resample_table.hpp", "srcnn_weights.inc",
+SOURCES = ["srcnn_kernels.hip", "srcnn_fused_f16.hip", "srcnn_capi.cpp", "srcnn_pipeline.cpp", "srcnn_comm.cpp", "dropin.cpp"]
+DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "srcnn_host.hpp", "resample_table.hpp", "srcnn_weights.inc",
                   "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h"]
 
 # -ffp-contract=off: strict kernels and the host table builder must round every multiply and add

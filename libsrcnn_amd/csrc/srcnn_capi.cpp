@@ -1,4 +1,6 @@
-// srcnn_capi.cpp -- the extern "C" boundary (include/srcnn_amd.h) over the gfx950 kernels.
+// srcnn_capi.cpp -- the extern "C" boundary (include/srcnn_amd.h) over the gfx950 kernels: contexts, plumbing and the
+// device-resident hot path.  The host-pointer pipelines (frame stream, ProcessSRCNN surface, node-level calls) are in
+// srcnn_pipeline.cpp; the state both share is srcnn_host.hpp.
 //
 // Host-side orchestration only: argument validation with the reference's return codes
 // (src/libsrcnn.cpp:951-966), lazily built + cached contribution tables
@@ -6,40 +8,28 @@
 // launch sequence that stands in for the body of libsrcnn::doSRCNN (src/libsrcnn.cpp:628-923).
 // There is deliberately no CPU compute path in this file: if HIP is unusable the calls fail.
 #include <hip/hip_runtime.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
+#include <string>
 #include <thread>
-#include <tuple>
-#include <vector>
 
-#include "../../include/srcnn_amd.h"
 #include "resample_table.hpp"
-#include "srcnn_kernels.h"
-
-namespace {
-
-using namespace srcnn;
-
-thread_local char g_err[512] = "";
-
-}  // namespace
+#include "srcnn_host.hpp"
 
 namespace srcnn {
-// shared with srcnn_comm.cpp so that srcnn_last_error() also reports RCCL failures
-void set_last_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
-}  // namespace srcnn
 
 namespace {
+thread_local char g_err[512] = "";
+thread_local int t_ctx = 0;            // the calling thread's current context (srcnn_set_context)
+}  // namespace
+
+void set_last_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+const char* last_error() { return g_err; }
 
 int fail(int code, const char* fmt, ...)
 {
@@ -50,138 +40,33 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(SRCNN_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+Global::Global()
+{
+    const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
+    const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
+    ws_budget.store(std::max<size_t>(mb, 1) << 20);
+    auto flag = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
+    const char* sel = getenv("SRCNN_CONV12");
+    conv12_valu = sel && strcmp(sel, "valu") == 0;
+    const char* var = getenv("SRCNN_CONV12_VARIANT");
+    conv12_variant = var ? atoi(var) : 1;
+    f16_unfused = flag("SRCNN_F16_UNFUSED");
+    resample_two_pass = flag("SRCNN_RESAMPLE_2PASS");
+    resample_old2d = flag("SRCNN_RESAMPLE_OLD2D");
+    shell_unfused = flag("SRCNN_SHELL_UNFUSED");
+    const char* nu = getenv("SRCNN_NUMA");
+    numa = !(nu && atoi(nu) == 0);
+}
+
+// Never destroyed: at process exit the HIP runtime may already be gone when static destructors run, and the
+// tables' destructors call hipFree.  srcnn_shutdown() is the orderly way to release everything.
+Global& G = *new Global;
+
+namespace {
 
 const uint32_t kWeightBits[kWeightCount] = {
 #include "srcnn_weights.inc"
 };
-
-struct DeviceTable {          // one uploaded AxisTable; freed only when the last reference goes
-    int* first = nullptr;
-    int* taps = nullptr;
-    double* weight = nullptr;
-    int stride = 0;
-    int max_taps = 0;
-    unsigned long long stamp = 0;      // LRU clock of the cache
-    DeviceTable() = default;
-    DeviceTable(const DeviceTable&) = delete;
-    DeviceTable& operator=(const DeviceTable&) = delete;
-    ~DeviceTable() { (void)hipFree(first); (void)hipFree(taps); (void)hipFree(weight); }
-    DevAxisTable view() const { return DevAxisTable{first, taps, weight, stride, max_taps}; }
-};
-using TableRef = std::shared_ptr<DeviceTable>;
-
-struct Workspace {          // scratch of one stream / graph / ProcessSRCNN lane; grow-only
-    std::mutex mu;          // held while a call enqueues work that uses this scratch
-    float* tmp = nullptr;   size_t tmp_n = 0;    // first resampler pass
-    float* up = nullptr;    size_t up_n = 0;     // upscaled Y (band)
-    float* c2 = nullptr;    size_t c2_n = 0;     // 32 layer-2 planes (band)
-    float* planes = nullptr; size_t planes_n = 0; // colour shell: split + resized chroma planes
-    unsigned char* bytes = nullptr; size_t bytes_n = 0;
-    bool frozen = false;    // a captured graph has these pointers baked in: growing is an error
-    void release()
-    {
-        (void)hipFree(tmp); (void)hipFree(up); (void)hipFree(c2); (void)hipFree(planes); (void)hipFree(bytes);
-        tmp = up = c2 = planes = nullptr; bytes = nullptr;
-        tmp_n = up_n = c2_n = planes_n = bytes_n = 0;
-    }
-};
-
-// One invocation of the path: where it runs, on which scratch, with which numerics.  The mode is read ONCE at the
-// public entry point, so a concurrent srcnn_set_mode never changes a call half way through, and `timing` is how a
-// graph capture tells the stage timers to stay out (event pairs cannot be timed inside a capture) without touching
-// any process-global setting.  `hold` keeps every contribution table the call launches with referenced: for an
-// eager call until the call returns (the cache itself only frees after a device sync), for a graph until the graph
-// is destroyed.
-struct Call {
-    hipStream_t s = nullptr;
-    Workspace* ws = nullptr;
-    int mode = SRCNN_MODE_STRICT;
-    bool timing = true;
-    std::vector<TableRef>* hold = nullptr;
-    bool strict() const { return mode == SRCNN_MODE_STRICT; }
-};
-
-struct StageSpan { hipEvent_t a, b; int stage; };
-
-struct StreamSlot {         // one lane of the host-stream path; lives until srcnn_shutdown
-    hipStream_t st = nullptr;          // kernels (slot 0's stream carries the kernels of BOTH slots, see the stream entry point)
-    hipStream_t cst = nullptr;         // this slot's copies, in both directions
-    hipEvent_t e_in = nullptr, e_k = nullptr, e_out = nullptr;   // frame landed / kernels done / result copied out
-    float* din = nullptr;  size_t din_n = 0;
-    float* dout = nullptr; size_t dout_n = 0;
-    Workspace ws;                      // private: the captured graph has its pointers baked in
-    std::vector<TableRef> tables;      // ... and these tables
-    hipGraphExec_t exec = nullptr;     // captured kernel sequence for (gw, gh, gmode)
-    unsigned gw = 0, gh = 0; int gmode = -1;
-    unsigned uses = 0;                 // eager runs at the current shape (capture needs one first)
-};
-
-// One lane of srcnn_process_u8 (the ProcessSRCNN surface).  The reference's ProcessSRCNN allocates everything per
-// call and is therefore re-entrant (src/libsrcnn.cpp:628-923); here a call leases a lane -- its own compute and
-// copy streams, scratch, page-locked staging and events -- for its whole duration, so concurrent calls from several
-// host threads never share a buffer.  Lanes are created on demand up to kMaxLanes; further callers wait for one.
-struct ProcLane {
-    bool busy = false;
-    hipStream_t st = nullptr, copy_st = nullptr;
-    Workspace ws;
-    unsigned char* pin_in = nullptr;  size_t pin_in_n = 0;
-    unsigned char* pin_out = nullptr; size_t pin_out_n = 0;
-    std::vector<hipEvent_t> band_events;
-    void release()
-    {
-        ws.release();
-        if (pin_in) (void)hipHostFree(pin_in);
-        if (pin_out) (void)hipHostFree(pin_out);
-        pin_in = pin_out = nullptr; pin_in_n = pin_out_n = 0;
-        for (auto e : band_events) (void)hipEventDestroy(e);
-        band_events.clear();
-        if (st) (void)hipStreamDestroy(st);
-        if (copy_st) (void)hipStreamDestroy(copy_st);
-        st = copy_st = nullptr;
-    }
-};
-constexpr size_t kMaxLanes = 4;
-constexpr size_t kMaxTables = 64;      // cache bound; only unreferenced tables are ever evicted
-
-struct Context {
-    std::mutex mu;
-    std::atomic<bool> profiling{false};
-    std::vector<StageSpan> spans;          // recorded, not yet read
-    std::vector<hipEvent_t> event_pool;    // recycled events
-    double stage_ms[SRCNN_STAGE_COUNT] = {0, 0, 0};
-    unsigned long long stage_n[SRCNN_STAGE_COUNT] = {0, 0, 0};
-    bool ready = false;
-    int device = 0;
-    std::atomic<int> mode{SRCNN_MODE_STRICT};
-    std::atomic<size_t> ws_budget{[] {      // bytes of layer-2 scratch one band may take (srcnn_set_workspace_limit)
-        const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
-        const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
-        return std::max<size_t>(mb, 1) << 20;
-    }()};
-    int num_cus = 256;
-    int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
-    bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
-    FusedF16Weights* fused_w = nullptr;   // device copy of the fused fp16 kernel's weight image
-    bool resample_two_pass = false;   // SRCNN_RESAMPLE_2PASS=1: always the two separate resampler passes (A/B testing)
-    bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
-    std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
-    unsigned long long table_clock = 0;
-    std::map<hipStream_t, std::unique_ptr<Workspace>> ws;
-    StreamSlot slots[2];
-    std::mutex stream_mu;               // srcnn_y_upscale2x_f32_stream is serialised
-    std::mutex lane_mu;                 // ProcessSRCNN lanes
-    std::condition_variable lane_cv;
-    std::vector<std::unique_ptr<ProcLane>> lanes;
-};
-
-// Never destroyed: at process exit the HIP runtime may already be gone when static destructors run, and the
-// tables' destructors call hipFree.  srcnn_shutdown() is the orderly way to release everything.
-Context& g = *new Context;
 
 void build_dev_weights(DevWeights& d)
 {
@@ -252,87 +137,145 @@ void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
     f.b3 = d.b3;
 }
 
-int ensure_init_locked(int device)
+
+// Host NUMA node next to a device: /sys/bus/pci/devices/<bdf>/numa_node (-1 when the platform does not say).
+int device_numa_node(int device)
 {
-    if (g.ready) {
-        if (device >= 0 && device != g.device)
-            return fail(SRCNN_E_ARG, "srcnn_init: already bound to device %d (asked for %d)", g.device, device);
-        return SRCNN_OK;
-    }
+    char bdf[64] = "";
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* p = bdf; *p; ++p) *p = (char)tolower(*p);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+// Create and initialise one context on `device` (caller holds G.mu).
+int make_context_locked(int device)
+{
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         return fail(SRCNN_E_NODEVICE, "no HIP device visible (%s); this library has no CPU path",
                     e == hipSuccess ? "count=0" : hipGetErrorString(e));
-    if (device < 0) device = 0;
-    if (device >= n) return fail(SRCNN_E_ARG, "device %d out of range (have %d)", device, n);
+    if (device < 0 || device >= n) return fail(SRCNN_E_ARG, "device %d out of range (have %d)", device, n);
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(SRCNN_E_NODEVICE, "device %d is %s; this build only carries gfx950 code", device, prop.gcnArchName);
+    auto cx = std::make_unique<Ctx>();
+    cx->index = (int)G.ctxs.size();
+    cx->device = device;
+    // __constant__ weights, the kernels' dynamic-LDS attributes and the fused tier's weight image are per DEVICE; a second
+    // (virtual) context on the same device re-uploads identical bytes
     auto dw = std::make_unique<DevWeights>();
     build_dev_weights(*dw);
     HIP_TRY(upload_weights(*dw));
     HIP_TRY(conv12_mfma_prepare());
     HIP_TRY(conv12_f16_prepare());
-    {
-        auto fw = std::make_unique<FusedF16Weights>();
-        build_fused_f16_weights(*dw, *fw);
-        if (!g.fused_w) HIP_TRY(hipMalloc((void**)&g.fused_w, sizeof(FusedF16Weights)));
-        HIP_TRY(hipMemcpy(g.fused_w, fw.get(), sizeof(FusedF16Weights), hipMemcpyHostToDevice));
-        HIP_TRY(fused_f16_prepare());
-        const char* uf = getenv("SRCNN_F16_UNFUSED");
-        g.f16_unfused = uf && atoi(uf) != 0;
-        const char* r2 = getenv("SRCNN_RESAMPLE_2PASS");
-        g.resample_two_pass = r2 && atoi(r2) != 0;
+    auto fw = std::make_unique<FusedF16Weights>();
+    build_fused_f16_weights(*dw, *fw);
+    HIP_TRY(hipMalloc((void**)&cx->fused_w, sizeof(FusedF16Weights)));
+    HIP_TRY(hipMemcpy(cx->fused_w, fw.get(), sizeof(FusedF16Weights), hipMemcpyHostToDevice));
+    HIP_TRY(fused_f16_prepare());
+    cx->num_cus = prop.multiProcessorCount;
+    cx->numa_node = device_numa_node(device);
+    // direct copies between the devices of a node (the node-level tiled frame moves its bands with hipMemcpyPeerAsync)
+    for (auto& other : G.ctxs) {
+        if (other->device == device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, other->device) == hipSuccess && can) {
+            (void)hipSetDevice(device); (void)hipDeviceEnablePeerAccess(other->device, 0);
+            (void)hipSetDevice(other->device); (void)hipDeviceEnablePeerAccess(device, 0);
+            (void)hipGetLastError();               // "already enabled" is fine
+            (void)hipSetDevice(device);
+        }
     }
-    g.num_cus = prop.multiProcessorCount;
-    const char* sel = getenv("SRCNN_CONV12");
-    g.conv12_valu = sel && strcmp(sel, "valu") == 0;
-    const char* var = getenv("SRCNN_CONV12_VARIANT");
-    g.conv12_variant = var ? atoi(var) : 1;
-    g.device = device;
-    g.ready = true;
+    G.ctxs.push_back(std::move(cx));
+    G.nctx.store((int)G.ctxs.size());
     return SRCNN_OK;
 }
+
+// env SRCNN_DEVICES for a process that never calls srcnn_init*: "all", or a comma list of device ids (an id may repeat:
+// virtual contexts on one device).  Unset: device 0.
+int lazy_init_locked()
+{
+    if (!G.ctxs.empty()) return SRCNN_OK;
+    const char* env = getenv("SRCNN_DEVICES");
+    std::vector<int> devs;
+    if (env && *env) {
+        if (strcmp(env, "all") == 0) {
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+            for (int d = 0; d < n; ++d) devs.push_back(d);
+        } else {
+            for (const char* p = env; *p;) {
+                char* end = nullptr;
+                const long v = strtol(p, &end, 10);
+                if (end == p) return fail(SRCNN_E_ARG, "SRCNN_DEVICES=%s: expected \"all\" or a comma list of device ids", env);
+                devs.push_back((int)v);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+    }
+    if (devs.empty()) devs.push_back(0);
+    for (int d : devs) {
+        int rc = make_context_locked(d);
+        if (rc) return rc;
+    }
+    return SRCNN_OK;
+}
+
+}  // namespace
 
 int ensure_init()
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    int rc = ensure_init_locked(-1);
-    if (rc == SRCNN_OK) {
-        // a thread other than the one that called srcnn_init still needs the device selected
-        hipError_t e = hipSetDevice(g.device);
-        if (e != hipSuccess) return fail(SRCNN_E_HIP, "hipSetDevice(%d) -> %s", g.device, hipGetErrorString(e));
-    }
-    return rc;
+    if (G.nctx.load(std::memory_order_acquire) > 0) return SRCNN_OK;
+    std::lock_guard<std::mutex> lk(G.mu);
+    return lazy_init_locked();
 }
 
-template <class T>
-int grow(T*& p, size_t& have, size_t want)
+int context_count() { return G.nctx.load(std::memory_order_acquire); }
+
+Ctx* context_at(int k)
 {
-    if (want <= have) return SRCNN_OK;
-    if (p) {
-        // kernels launched earlier (any stream) may still be using the old block: drain before freeing it
-        (void)hipDeviceSynchronize();
-        (void)hipFree(p);
-        p = nullptr; have = 0;
-    }
-    void* q = nullptr;
-    if (hipMalloc(&q, want * sizeof(T)) != hipSuccess)
-        return fail(SRCNN_E_DEVMEM, "hipMalloc(%zu bytes) failed", want * sizeof(T));
-    p = static_cast<T*>(q);
-    have = want;
+    std::lock_guard<std::mutex> lk(G.mu);
+    return (k >= 0 && k < (int)G.ctxs.size()) ? G.ctxs[k].get() : nullptr;
+}
+
+int bind(Ctx& cx)
+{
+    hipError_t e = hipSetDevice(cx.device);
+    if (e != hipSuccess) return fail(SRCNN_E_HIP, "hipSetDevice(%d) -> %s", cx.device, hipGetErrorString(e));
     return SRCNN_OK;
 }
 
-template <class T>
-int grow_ws(Workspace& ws, T*& p, size_t& have, size_t want)
+Ctx* cur_ctx()
 {
-    if (want <= have) return SRCNN_OK;
-    if (ws.frozen) return fail(SRCNN_E_ARG, "workspace of a captured graph cannot grow (%zu > %zu elements)", want, have);
-    return grow(p, have, want);
+    if (ensure_init()) return nullptr;
+    Ctx* cx = context_at(t_ctx);
+    if (!cx) cx = context_at(0);
+    if (!cx) { fail(SRCNN_E_NODEVICE, "no context"); return nullptr; }
+    if (bind(*cx)) return nullptr;                 // a thread other than the one that called srcnn_init still needs the device selected
+    return cx;
+}
+
+Ctx* ctx_for_stream(void* stream)
+{
+    if (ensure_init()) return nullptr;
+    Ctx* cx = nullptr;
+    if (stream) {
+        std::lock_guard<std::mutex> lk(G.mu);
+        auto it = G.stream_ctx.find((hipStream_t)stream);
+        if (it != G.stream_ctx.end() && it->second < (int)G.ctxs.size()) cx = G.ctxs[it->second].get();
+    }
+    if (!cx) return cur_ctx();
+    if (bind(*cx)) return nullptr;
+    return cx;
 }
 
 // Look up / build / upload the contribution table of one axis.  The cache holds one reference, the caller gets
@@ -341,63 +284,196 @@ int grow_ws(Workspace& ws, T*& p, size_t& have, size_t want)
 // resample, not one another thread is about to launch with, not one baked into a captured graph.
 int get_table(Call& c, int filter, unsigned dst_len, unsigned src_len, TableRef& out)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
+    Ctx& cx = *c.cx;
+    std::lock_guard<std::mutex> lk(cx.mu);
     const auto key = std::make_tuple(filter, dst_len, src_len);
-    auto it = g.tables.find(key);
-    if (it == g.tables.end()) {
+    auto it = cx.tables.find(key);
+    if (it == cx.tables.end()) {
         const AxisTable t = build_axis_table(filter, dst_len, src_len);
         auto d = std::make_shared<DeviceTable>();
         d->stride = t.stride;
         d->max_taps = t.max_taps;
+        d->h_first.assign(t.first.begin(), t.first.end());
+        d->h_taps.assign(t.taps.begin(), t.taps.end());
+        d->monotone = true;
+        for (unsigned u = 1; u < dst_len; ++u)
+            if (t.first[u] < t.first[u - 1] || t.first[u] + t.taps[u] < t.first[u - 1] + t.taps[u - 1]) { d->monotone = false; break; }
         HIP_TRY(hipMalloc((void**)&d->first, sizeof(int) * dst_len));
         HIP_TRY(hipMalloc((void**)&d->taps, sizeof(int) * dst_len));
         HIP_TRY(hipMalloc((void**)&d->weight, sizeof(double) * t.weight.size()));
         HIP_TRY(hipMemcpy(d->first, t.first.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->taps, t.taps.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d->weight, t.weight.data(), sizeof(double) * t.weight.size(), hipMemcpyHostToDevice));
-        if (g.tables.size() >= kMaxTables) {
+        if (cx.tables.size() >= kMaxTables) {
             // evict the least recently used tables that only the cache still references, down to half the bound.
             // Kernels launched by calls that already returned may still be reading them, hence the drain first.
             std::vector<std::pair<unsigned long long, std::tuple<int, unsigned, unsigned>>> idle;
-            for (auto& kv : g.tables)
+            for (auto& kv : cx.tables)
                 if (kv.second.use_count() == 1) idle.emplace_back(kv.second->stamp, kv.first);
             std::sort(idle.begin(), idle.end());
             if (!idle.empty()) (void)hipDeviceSynchronize();
             for (auto& e : idle) {
-                if (g.tables.size() < kMaxTables / 2) break;
-                g.tables.erase(e.second);
+                if (cx.tables.size() < kMaxTables / 2) break;
+                cx.tables.erase(e.second);
             }
         }
-        it = g.tables.emplace(key, std::move(d)).first;
+        it = cx.tables.emplace(key, std::move(d)).first;
     }
-    it->second->stamp = ++g.table_clock;
+    it->second->stamp = ++cx.table_clock;
     out = it->second;
     if (c.hold) c.hold->push_back(out);
     return SRCNN_OK;
 }
 
-Workspace* workspace_for(hipStream_t s)
+Workspace* workspace_for(Ctx& cx, hipStream_t s)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    auto& p = g.ws[s];
+    std::lock_guard<std::mutex> lk(cx.mu);
+    auto& p = cx.ws[s];
     if (!p) p = std::make_unique<Workspace>();
     return p.get();
 }
 
+// Page-locked host memory for a context's staging: portable (every device of the node may DMA to it -- the node-level
+// ProcessSRCNN shares one output staging), and placed on the NUMA node next to the device when the platform tells us
+// which one that is (hipHostMallocNumaUser: the allocation follows the calling thread's memory policy, which is set to
+// "prefer that node" around the call).  SRCNN_NUMA=0 disables the placement.
+void* pinned_alloc(Ctx& cx, size_t bytes)
+{
+    void* p = nullptr;
+    const bool place = G.numa && cx.numa_node >= 0 && cx.numa_node < 1024;
+    unsigned long mask[16] = {0};
+    if (place) {
+        mask[cx.numa_node / (8 * sizeof(unsigned long))] |= 1ul << (cx.numa_node % (8 * sizeof(unsigned long)));
+        if (syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul) != 0) mask[0] = 0;
+    }
+    unsigned flags = hipHostMallocPortable | (place ? hipHostMallocNumaUser : 0u);
+    if (hipHostMalloc(&p, bytes ? bytes : 1, flags) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+        if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    }
+    if (place) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+    if (!p) fail(SRCNN_E_DEVMEM, "hipHostMalloc(%zu) failed", bytes);
+    return p;
+}
+
+int grow_pinned(Ctx& cx, unsigned char*& p, size_t& have, size_t want)
+{
+    if (want <= have) return SRCNN_OK;
+    if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; have = 0; }
+    p = static_cast<unsigned char*>(pinned_alloc(cx, want));
+    if (!p) return SRCNN_E_DEVMEM;
+    have = want;
+    return SRCNN_OK;
+}
+
+void parallel_memcpy(void* dst, const void* src, size_t n)
+{
+    const size_t kChunk = 4u << 20;
+    unsigned nt = (unsigned)std::min<size_t>(8, n / kChunk);
+    if (nt <= 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((n / nt) + 4095) & ~size_t(4095);
+    size_t done = 0;                    // bytes handed to threads that actually started
+    try {
+        for (unsigned t = 1; t < nt; ++t) {
+            const size_t off = (size_t)t * per;
+            if (off >= n) break;
+            const size_t len = std::min(per, n - off);
+            th.emplace_back([=] { memcpy((char*)dst + off, (const char*)src + off, len); });
+            done = off + len;
+        }
+    } catch (...) {                     // thread creation failed: the rest is copied here
+        done = th.empty() ? 0 : done;
+    }
+    // this thread takes the first chunk (and whatever could not be handed out)
+    memcpy(dst, src, std::min(per, n));
+    const size_t covered = th.empty() ? std::min(per, n) : done;
+    if (covered < n) memcpy((char*)dst + covered, (const char*)src + covered, n - covered);
+    for (auto& t : th) t.join();
+}
+
+void ProcLane::release_buffers()
+{
+    ws.release();
+    if (pin_in) (void)hipHostFree(pin_in);
+    if (pin_out) (void)hipHostFree(pin_out);
+    pin_in = pin_out = nullptr; pin_in_n = pin_out_n = 0;
+}
+
+void ProcLane::release()
+{
+    release_buffers();
+    for (auto e : band_events) (void)hipEventDestroy(e);
+    band_events.clear();
+    if (st) (void)hipStreamDestroy(st);
+    if (copy_st) (void)hipStreamDestroy(copy_st);
+    st = copy_st = nullptr;
+}
+
+void NodeLane::release()
+{
+    ws.release();
+    (void)hipFree(in); (void)hipFree(band);
+    in = band = nullptr; in_n = band_n = 0;
+    for (auto e : events) (void)hipEventDestroy(e);
+    events.clear();
+    if (st) (void)hipStreamDestroy(st);
+    if (copy_st) (void)hipStreamDestroy(copy_st);
+    st = copy_st = nullptr;
+}
+
+LaneLease::LaneLease(Ctx& c) : cx(&c)
+{
+    std::unique_lock<std::mutex> lk(c.lane_mu);
+    for (;;) {
+        for (auto& l : c.lanes)
+            if (!l->busy) { lane = l.get(); break; }
+        if (lane) break;
+        if (c.lanes.size() < kMaxLanes) {
+            auto l = std::make_unique<ProcLane>();
+            if (hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&l->copy_st, hipStreamNonBlocking) != hipSuccess) {
+                l->release();
+                rc = fail(SRCNN_E_HIP, "could not create the streams of a ProcessSRCNN lane");
+                return;
+            }
+            c.lanes.push_back(std::move(l));
+            lane = c.lanes.back().get();
+            break;
+        }
+        c.lane_cv.wait(lk);
+    }
+    lane->busy = true;
+}
+
+LaneLease::~LaneLease()
+{
+    if (!lane) return;
+    // nothing of this call may still be running on the lane when the next caller takes it
+    (void)hipSetDevice(cx->device);
+    (void)hipStreamSynchronize(lane->st);
+    (void)hipStreamSynchronize(lane->copy_st);
+    { std::lock_guard<std::mutex> lk(cx->lane_mu); lane->busy = false; }
+    cx->lane_cv.notify_one();
+}
+
+namespace {
+
 // RAII bracket: records an event pair around one stage on the launch stream when profiling is on.
 struct StageTimer {
-    hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool on;
-    static hipEvent_t take()
+    Ctx& cx; hipStream_t s; int stage; hipEvent_t a = nullptr, b = nullptr; bool on;
+    hipEvent_t take()
     {
-        if (!g.event_pool.empty()) { hipEvent_t e = g.event_pool.back(); g.event_pool.pop_back(); return e; }
+        if (!cx.event_pool.empty()) { hipEvent_t e = cx.event_pool.back(); cx.event_pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
-    StageTimer(int stage_, const Call& c) : s(c.s), stage(stage_), on(c.timing && g.profiling.load(std::memory_order_relaxed))
+    StageTimer(int stage_, const Call& c) : cx(*c.cx), s(c.s), stage(stage_), on(c.timing && G.profiling.load(std::memory_order_relaxed))
     {
         if (!on) return;
-        std::lock_guard<std::mutex> lk(g.mu);
+        std::lock_guard<std::mutex> lk(cx.mu);
         a = take(); b = take();
         if (!a || !b) { on = false; return; }
         (void)hipEventRecord(a, s);
@@ -406,23 +482,23 @@ struct StageTimer {
     {
         if (!on) return;
         (void)hipEventRecord(b, s);
-        std::lock_guard<std::mutex> lk(g.mu);
-        g.spans.push_back(StageSpan{a, b, stage});
+        std::lock_guard<std::mutex> lk(cx.mu);
+        cx.spans.push_back(StageSpan{a, b, stage});
     }
 };
 
-void drain_spans_locked()
+void drain_spans_locked(Ctx& cx)
 {
-    for (auto& sp : g.spans) {
+    for (auto& sp : cx.spans) {
         float ms = 0.f;
         if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-            g.stage_ms[sp.stage] += ms;
-            g.stage_n[sp.stage] += 1;
+            cx.stage_ms[sp.stage] += ms;
+            cx.stage_n[sp.stage] += 1;
         }
-        g.event_pool.push_back(sp.a);
-        g.event_pool.push_back(sp.b);
+        cx.event_pool.push_back(sp.a);
+        cx.event_pool.push_back(sp.b);
     }
-    g.spans.clear();
+    cx.spans.clear();
 }
 
 // Y holds rows [y_row_base, y_row_base + y_rows) of the (W x H) upscaled plane; the kernels clamp their halo
@@ -430,9 +506,79 @@ void drain_spans_locked()
 void run_conv12(const Call& c, const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane, int row0,
                 int rows)
 {
-    if (c.mode == SRCNN_MODE_FAST_F16) launch_conv12_f16(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, g.num_cus, c.s);
-    else if (g.conv12_valu) launch_conv12(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.s);
-    else launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), g.num_cus, g.conv12_variant, c.s);
+    if (c.mode == SRCNN_MODE_FAST_F16) launch_conv12_f16(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.cx->num_cus, c.s);
+    else if (G.conv12_valu) launch_conv12(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.s);
+    else launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.cx->num_cus, G.conv12_variant, c.s);
+}
+
+DevAxisTable view_of(const TableRef& t) { return t->view(); }
+
+// FRAWResizeEngine::scale (src/frawscale.cpp:162-286) for destination rows [r0,r1) only, from either kind of source.
+// dst holds rows [r0,r1) (row r0 at offset 0).  tmp is scratch from the call's workspace.
+int resample_src_rows(Call& c, const YSource& src, unsigned sw, unsigned sh, unsigned dw, unsigned dh, int filter,
+                      unsigned r0, unsigned r1, float* d_dst)
+{
+    Workspace& ws = *c.ws;
+    hipStream_t s = c.s;
+    const float* d_in = src.plane;
+    if (sw == dw && sh == dh) {
+        // The reference's identity branch copies sizeof(unsigned short) bytes per pixel into an
+        // uninitialised buffer (src/frawscale.cpp:185-193), i.e. half the plane is garbage.  We copy the
+        // whole plane (the evident intent); documented in DESIGN.md as the one deliberate deviation and pinned by
+        // tests/test_gpu_parity.py::test_identity_size_deviation_is_pinned.
+        if (!d_in) return fail(SRCNN_E_UNSUPPORTED, "identity-size resample needs a float plane");
+        HIP_TRY(hipMemcpyAsync(d_dst, d_in + (size_t)r0 * sw, sizeof(float) * (size_t)(r1 - r0) * sw,
+                               hipMemcpyDeviceToDevice, s));
+        return SRCNN_OK;
+    }
+    TableRef tv, th;
+    int rc;
+    if (dw > sw && sh != dh) {
+        // up-scale in both axes: vertical first, then horizontal (src/frawscale.cpp:238-278), both in one kernel
+        if ((rc = get_table(c, filter, dw, sw, th))) return rc;
+        if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
+        if (!G.resample_two_pass && !G.resample_old2d &&
+            launch_rs2d(src, sw, sh, d_dst, dw, dh, r0, r1 - r0, view_of(tv), view_of(th), s)) return SRCNN_OK;
+    }
+    if (!d_in) return fail(SRCNN_E_UNSUPPORTED, "this resample shape needs a float source plane");
+    if (dw <= sw) {
+        // horizontal first over all source rows, then vertical (src/frawscale.cpp:195-237)
+        const float* mid = d_in;
+        if (sw != dw) {
+            if ((rc = get_table(c, filter, dw, sw, th))) return rc;
+            if (sh != dh) {
+                if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)dw * sh))) return rc;
+                launch_resample_rows(d_in, sw, ws.tmp, dw, sh, view_of(th), s);
+                mid = ws.tmp;
+            } else {
+                launch_resample_rows(d_in + (size_t)r0 * sw, sw, d_dst, dw, r1 - r0, view_of(th), s);
+                return SRCNN_OK;
+            }
+        }
+        if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
+        launch_resample_cols(mid, dw, 0, d_dst, r0, r1 - r0, view_of(tv), s);
+    } else {
+        // vertical first, then horizontal (src/frawscale.cpp:238-278)
+        if (!th && (rc = get_table(c, filter, dw, sw, th))) return rc;
+        const float* mid = d_in + (size_t)r0 * sw;
+        if (sh != dh) {
+            if (!tv && (rc = get_table(c, filter, dh, sh, tv))) return rc;
+            if (!G.resample_two_pass && launch_resample_2d(d_in, sw, sh, d_dst, dw, dh, r0, r1 - r0, view_of(tv), view_of(th), s)) return SRCNN_OK;
+            if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
+            launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, view_of(tv), s);
+            mid = ws.tmp;
+        }
+        launch_resample_rows(mid, sw, d_dst, dw, r1 - r0, view_of(th), s);
+    }
+    return SRCNN_OK;
+}
+
+}  // namespace
+
+int resample_rows_range(Call& c, const float* d_in, unsigned sw, unsigned sh, unsigned dw, unsigned dh, int filter,
+                        unsigned r0, unsigned r1, float* d_dst)
+{
+    return resample_src_rows(c, YSource::from_plane(d_in), sw, sh, dw, dh, filter, r0, r1, d_dst);
 }
 
 int check_plane(const void* in, unsigned w, unsigned h, const void* out)
@@ -442,80 +588,32 @@ int check_plane(const void* in, unsigned w, unsigned h, const void* out)
     return SRCNN_OK;
 }
 
-// FRAWResizeEngine::scale (src/frawscale.cpp:162-286) for destination rows [r0,r1) only.
-// dst holds rows [r0,r1) (row r0 at offset 0).  tmp is scratch from the call's workspace.
-int resample_rows_range(Call& c, const float* d_in, unsigned sw, unsigned sh, unsigned dw, unsigned dh, int filter,
-                        unsigned r0, unsigned r1, float* d_dst)
-{
-    Workspace& ws = *c.ws;
-    hipStream_t s = c.s;
-    if (sw == dw && sh == dh) {
-        // The reference's identity branch copies sizeof(unsigned short) bytes per pixel into an
-        // uninitialised buffer (src/frawscale.cpp:185-193), i.e. half the plane is garbage.  We copy the
-        // whole plane (the evident intent); documented in DESIGN.md as the one deliberate deviation.
-        HIP_TRY(hipMemcpyAsync(d_dst, d_in + (size_t)r0 * sw, sizeof(float) * (size_t)(r1 - r0) * sw,
-                               hipMemcpyDeviceToDevice, s));
-        return SRCNN_OK;
-    }
-    TableRef tv, th;
-    int rc;
-    if (dw <= sw) {
-        // horizontal first over all source rows, then vertical (src/frawscale.cpp:195-237)
-        const float* mid = d_in;
-        if (sw != dw) {
-            if ((rc = get_table(c, filter, dw, sw, th))) return rc;
-            if (sh != dh) {
-                if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)dw * sh))) return rc;
-                launch_resample_rows(d_in, sw, ws.tmp, dw, sh, th->view(), s);
-                mid = ws.tmp;
-            } else {
-                launch_resample_rows(d_in + (size_t)r0 * sw, sw, d_dst, dw, r1 - r0, th->view(), s);
-                return SRCNN_OK;
-            }
-        }
-        if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
-        launch_resample_cols(mid, dw, 0, d_dst, r0, r1 - r0, tv->view(), s);
-    } else {
-        // vertical first, then horizontal (src/frawscale.cpp:238-278)
-        if ((rc = get_table(c, filter, dw, sw, th))) return rc;
-        const float* mid = d_in + (size_t)r0 * sw;
-        if (sh != dh) {
-            if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
-            if (!g.resample_two_pass && launch_resample_2d(d_in, sw, sh, d_dst, dw, dh, r0, r1 - r0, tv->view(), th->view(), s)) return SRCNN_OK;
-            if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
-            launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, tv->view(), s);
-            mid = ws.tmp;
-        }
-        launch_resample_rows(mid, sw, d_dst, dw, r1 - r0, th->view(), s);
-    }
-    return SRCNN_OK;
-}
-
 // resample + conv12 + conv3 for output rows [r0,r1) of the (dw x dh) result.
-int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
                 unsigned r0, unsigned r1, float* d_out)
 {
     if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
     if (dh > (1u << 20) || h > (1u << 20) || dw > 0x7fffffu || (r1 - r0) > 65535u * 16u)
         return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large", dw, dh);
     Workspace& ws = *c.ws;
+    Ctx& cx = *c.cx;
     // rows of layer-2 activations that conv3 touches (clamp-to-edge of the ACTIVATIONS at the true
     // border), and rows of upscaled Y that conv1 touches for those.
     const unsigned ca = r0 >= 2 ? r0 - 2 : 0, cb = std::min(dh, r1 + 2);
     const unsigned ua = ca >= 4 ? ca - 4 : 0, ub = std::min(dh, cb + 4);
     int rc;
     if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
-    const bool fused = c.mode == SRCNN_MODE_FAST_F16 && !g.f16_unfused;
+    const bool fused = c.mode == SRCNN_MODE_FAST_F16 && !G.f16_unfused;
     if (fused) {
         // non-parity tier: one kernel for all three layers, no layer-2 planes at all
         {
             StageTimer t(SRCNN_STAGE_RESAMPLE, c);
-            if ((rc = resample_rows_range(c, d_in, w, h, dw, dh, filter, ua, ub, ws.up))) return rc;
+            if ((rc = resample_src_rows(c, src, w, h, dw, dh, filter, ua, ub, ws.up))) return rc;
         }
         {
             StageTimer t(SRCNN_STAGE_CONV12, c);
-            launch_fused_f16(ws.up, (int)dw, (int)dh, (int)ua, (int)(ub - ua), d_out, (int)r0, (int)(r1 - r0), g.fused_w,
-                             g.num_cus, c.s);
+            launch_fused_f16(ws.up, (int)dw, (int)dh, (int)ua, (int)(ub - ua), d_out, (int)r0, (int)(r1 - r0), cx.fused_w,
+                             cx.num_cus, c.s);
         }
         HIP_TRY(hipGetLastError());
         return SRCNN_OK;
@@ -523,7 +621,7 @@ int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw,
     if ((rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
     {
         StageTimer t(SRCNN_STAGE_RESAMPLE, c);
-        if ((rc = resample_rows_range(c, d_in, w, h, dw, dh, filter, ua, ub, ws.up))) return rc;
+        if ((rc = resample_src_rows(c, src, w, h, dw, dh, filter, ua, ub, ws.up))) return rc;
     }
     const size_t plane = (size_t)dw * (cb - ca);
     {
@@ -539,22 +637,47 @@ int y_path_rows(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw,
     return SRCNN_OK;
 }
 
+// Source rows [lo,hi) of the (w x h) input that output rows [r0,r1) of the Y path depend on: +-2 rows of layer-2
+// activations, +-4 rows of upscaled Y for those, and the vertical taps of the resampler for that range -- read off the
+// contribution table itself, so it is exact for every filter and ratio.
+int y_path_source_rows(Call& c, unsigned h, unsigned dh, int filter, unsigned r0, unsigned r1, unsigned& lo, unsigned& hi)
+{
+    const unsigned ca = r0 >= 2 ? r0 - 2 : 0, cb = std::min(dh, r1 + 2);
+    const unsigned ua = ca >= 4 ? ca - 4 : 0, ub = std::min(dh, cb + 4);
+    if (h == dh) { lo = ua; hi = ub; return SRCNN_OK; }
+    TableRef tv;
+    int rc = get_table(c, filter, dh, h, tv);
+    if (rc) return rc;
+    tv->source_span(ua, ub, lo, hi);
+    hi = std::min(hi, h);
+    return SRCNN_OK;
+}
+
+unsigned budget_band_rows(unsigned dw)
+{
+    const size_t budget = G.ws_budget.load();
+    const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
+    const size_t fit = budget / row_bytes;
+    // 16-row floor: one tile row of the layer kernels (a smaller limit is exceeded rather than refused; srcnn_amd.h says so)
+    return (unsigned)std::min<size_t>(std::max<size_t>(16, fit > 4 ? fit - 4 : 1), 1u << 20);
+}
+
 // Output rows [r0,r1).  The 32 layer-2 planes are the big scratch (128 B per output pixel).  A range whose planes
 // would exceed the workspace budget (default 16 GiB, SRCNN_MAX_WORKSPACE_MB) is produced in horizontal bands --
 // bit-identical to the whole range -- so a 16K x 16K output needs the same scratch as an 8K one.
 int y_path_range(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
                  unsigned r0, unsigned r1, float* d_out)
 {
-    const size_t budget = g.ws_budget.load();
+    const size_t budget = G.ws_budget.load();
     if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
     const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
-    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !g.f16_unfused;      // the fused kernel has no layer-2 planes
-    if (no_planes || row_bytes * ((size_t)(r1 - r0) + 4) <= budget) return y_path_rows(c, d_in, w, h, dw, dh, filter, r0, r1, d_out);
-    const size_t fit = budget / row_bytes;
-    const unsigned band = (unsigned)std::max<size_t>(16, fit > 4 ? fit - 4 : 1);
+    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !G.f16_unfused;      // the fused kernel has no layer-2 planes
+    const YSource src = YSource::from_plane(d_in);
+    if (no_planes || row_bytes * ((size_t)(r1 - r0) + 4) <= budget) return y_path_rows(c, src, w, h, dw, dh, filter, r0, r1, d_out);
+    const unsigned band = budget_band_rows(dw);
     for (unsigned a = r0; a < r1; a += band) {
         const unsigned b = std::min(r1, a + band);
-        int rc = y_path_rows(c, d_in, w, h, dw, dh, filter, a, b, d_out + (size_t)(a - r0) * dw);
+        int rc = y_path_rows(c, src, w, h, dw, dh, filter, a, b, d_out + (size_t)(a - r0) * dw);
         if (rc) return rc;
     }
     return SRCNN_OK;
@@ -574,96 +697,90 @@ int check_y_path_args(const float* d_in, unsigned w, unsigned h, unsigned dw, un
     return SRCNN_OK;
 }
 
+namespace {
+
 // An eager call on a caller-visible stream: the stream's own scratch, locked while this call enqueues.
 struct StreamCall {
     std::vector<TableRef> tables;
     Call c;
     std::unique_lock<std::mutex> lk;
+    int rc = SRCNN_OK;
     explicit StreamCall(void* stream)
     {
+        c.cx = ctx_for_stream(stream);
+        if (!c.cx) { rc = SRCNN_E_NODEVICE; return; }
         c.s = (hipStream_t)stream;
-        c.ws = workspace_for(c.s);
-        c.mode = g.mode.load();
+        c.ws = workspace_for(*c.cx, c.s);
+        c.mode = G.mode.load();
         c.hold = &tables;
         lk = std::unique_lock<std::mutex>(c.ws->mu);
     }
 };
 
-int grow_pinned(unsigned char*& p, size_t& have, size_t want)
+int batch_frames(Call& c, const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out)
 {
-    if (want <= have) return SRCNN_OK;
-    if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; have = 0; }
-    void* q = nullptr;
-    if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return fail(SRCNN_E_DEVMEM, "hipHostMalloc(%zu) failed", want);
-    p = static_cast<unsigned char*>(q);
-    have = want;
+    const size_t in_n = (size_t)w * h, out_n = in_n * 4;
+    for (unsigned f = 0; f < nframes; ++f) {
+        int rc = y_path_frame(c, d_in + f * in_n, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out + f * out_n);
+        if (rc) return rc;
+    }
     return SRCNN_OK;
 }
 
-// memcpy split over a few host threads: the destination is usually a fresh new[] block whose pages fault in on
-// first touch, which a single thread does at only a few GB/s.
-void parallel_memcpy(void* dst, const void* src, size_t n)
-{
-    const size_t kChunk = 4u << 20;
-    unsigned nt = (unsigned)std::min<size_t>(8, n / kChunk);
-    if (nt <= 1) { memcpy(dst, src, n); return; }
-    std::vector<std::thread> th;
-    const size_t per = ((n / nt) + 4095) & ~size_t(4095);
-    for (unsigned t = 0; t < nt; ++t) {
-        const size_t off = (size_t)t * per;
-        if (off >= n) break;
-        const size_t len = std::min(per, n - off);
-        th.emplace_back([=] { memcpy((char*)dst + off, (const char*)src + off, len); });
-    }
-    for (auto& t : th) t.join();
-}
-
-// Lease of one ProcessSRCNN lane for the duration of a call.
-struct LaneLease {
-    ProcLane* lane = nullptr;
-    int rc = SRCNN_OK;
-    LaneLease()
-    {
-        std::unique_lock<std::mutex> lk(g.lane_mu);
-        for (;;) {
-            for (auto& l : g.lanes)
-                if (!l->busy) { lane = l.get(); break; }
-            if (lane) break;
-            if (g.lanes.size() < kMaxLanes) {
-                auto l = std::make_unique<ProcLane>();
-                if (hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking) != hipSuccess ||
-                    hipStreamCreateWithFlags(&l->copy_st, hipStreamNonBlocking) != hipSuccess) {
-                    l->release();
-                    rc = fail(SRCNN_E_HIP, "could not create the streams of a ProcessSRCNN lane");
-                    return;
-                }
-                g.lanes.push_back(std::move(l));
-                lane = g.lanes.back().get();
-                break;
-            }
-            g.lane_cv.wait(lk);
-        }
-        lane->busy = true;
-    }
-    ~LaneLease()
-    {
-        if (!lane) return;
-        // nothing of this call may still be running on the lane when the next caller takes it
-        (void)hipStreamSynchronize(lane->st);
-        (void)hipStreamSynchronize(lane->copy_st);
-        { std::lock_guard<std::mutex> lk(g.lane_mu); lane->busy = false; }
-        g.lane_cv.notify_one();
-    }
+// A captured batch owns everything its kernel nodes point at: its scratch and its contribution tables live exactly
+// as long as the handle, whatever happens to the stream's own workspace or to the table cache in the meantime.
+struct BatchGraph {
+    Ctx* cx = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t stream = nullptr;
+    Workspace ws;
+    std::vector<TableRef> tables;
 };
 
+void release_context(Ctx& cx)
+{
+    (void)hipSetDevice(cx.device);
+    (void)hipDeviceSynchronize();
+    {
+        std::lock_guard<std::mutex> lk(cx.lane_mu);
+        for (auto& l : cx.lanes) l->release();
+        cx.lanes.clear();
+    }
+    cx.node.release();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    cx.tables.clear();                        // graphs still alive keep their own references
+    for (auto& kv : cx.ws) kv.second->release();
+    cx.ws.clear();
+    for (auto& sl : cx.slots) {
+        if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
+        if (sl.st) (void)hipStreamDestroy(sl.st);
+        if (sl.cst) (void)hipStreamDestroy(sl.cst);
+        for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        (void)hipFree(sl.din); (void)hipFree(sl.dout);
+        sl.ws.release();
+        sl.tables.clear();
+        sl.graph_tables.clear();
+        sl.st = sl.cst = nullptr; sl.din = sl.dout = nullptr; sl.din_n = sl.dout_n = 0;
+        sl.exec = nullptr; sl.gw = sl.gh = 0; sl.gmode = -1; sl.uses = 0;
+    }
+    drain_spans_locked(cx);
+    for (auto e : cx.event_pool) (void)hipEventDestroy(e);
+    cx.event_pool.clear();
+    (void)hipFree(cx.fused_w);
+    cx.fused_w = nullptr;
+}
+
 }  // namespace
+}  // namespace srcnn
+
+using namespace srcnn;
 
 // ================================================================================================
 extern "C" {
 
 int srcnn_abi_version(void) { return SRCNN_AMD_ABI_VERSION; }
 
-const char* srcnn_last_error(void) { return g_err; }
+const char* srcnn_last_error(void) { return srcnn::last_error(); }
 
 int srcnn_device_count(void)
 {
@@ -674,68 +791,131 @@ int srcnn_device_count(void)
 
 int srcnn_init(int device)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    return ensure_init_locked(device);
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (!G.ctxs.empty()) {
+        if (device >= 0 && device != G.ctxs[0]->device)
+            return fail(SRCNN_E_ARG, "srcnn_init: already bound to device %d (asked for %d)", G.ctxs[0]->device, device);
+        return SRCNN_OK;
+    }
+    if (device < 0) return lazy_init_locked();
+    return make_context_locked(device);
 }
+
+int srcnn_init_devices(const int* devices, int n)
+{
+    std::lock_guard<std::mutex> lk(G.mu);
+    std::vector<int> want;
+    if (!devices || n <= 0) {
+        int have = 0;
+        if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return fail(SRCNN_E_NODEVICE, "no HIP device visible; this library has no CPU path");
+        for (int d = 0; d < have; ++d) want.push_back(d);
+    } else {
+        if (n > 64) return fail(SRCNN_E_ARG, "srcnn_init_devices: at most 64 contexts");
+        want.assign(devices, devices + n);
+    }
+    if (!G.ctxs.empty()) {
+        // idempotent for the same list; a prefix may be extended (srcnn_init(0) followed by srcnn_init_devices({0,1,..}))
+        for (size_t k = 0; k < G.ctxs.size(); ++k)
+            if (k >= want.size() || want[k] != G.ctxs[k]->device)
+                return fail(SRCNN_E_ARG, "srcnn_init_devices: context %zu is already bound to device %d; call srcnn_shutdown first",
+                            k, G.ctxs[k]->device);
+    }
+    for (size_t k = G.ctxs.size(); k < want.size(); ++k) {
+        int rc = make_context_locked(want[k]);
+        if (rc) return rc;
+    }
+    return SRCNN_OK;
+}
+
+int srcnn_context_count(void) { return context_count(); }
+
+int srcnn_context_device(int k)
+{
+    Ctx* cx = context_at(k);
+    return cx ? cx->device : fail(SRCNN_E_ARG, "no context %d", k);
+}
+
+int srcnn_set_context(int k)
+{
+    if (int rc = ensure_init()) return rc;
+    if (k < 0 || k >= context_count()) return fail(SRCNN_E_ARG, "no context %d (have %d)", k, context_count());
+    const int prev = t_ctx;
+    t_ctx = k;
+    Ctx* cx = context_at(k);
+    if (cx) (void)bind(*cx);
+    return prev;
+}
+
+int srcnn_get_context(void) { return t_ctx; }
 
 void srcnn_shutdown(void)
 {
+    srcnn_comm_destroy();
+    std::vector<std::unique_ptr<Ctx>> dying;
     {
-        std::lock_guard<std::mutex> lk(g.mu);
-        if (!g.ready) return;
+        std::lock_guard<std::mutex> lk(G.mu);
+        if (G.ctxs.empty()) return;
+        G.nctx.store(0);
+        dying.swap(G.ctxs);
+        G.stream_ctx.clear();
     }
-    (void)hipDeviceSynchronize();
-    {
-        std::lock_guard<std::mutex> lk(g.lane_mu);
-        for (auto& l : g.lanes) l->release();
-        g.lanes.clear();
+    for (auto& cx : dying) release_context(*cx);
+    t_ctx = 0;
+}
+
+// Release what idle lanes and unreferenced cache entries hold (scratch, page-locked staging, contribution tables) without
+// shutting the library down: a long-lived process that once handled a very large image gets its memory back.
+int srcnn_trim(void)
+{
+    if (int rc = ensure_init()) return rc;
+    for (int k = 0; k < context_count(); ++k) {
+        Ctx* cx = context_at(k);
+        if (!cx) continue;
+        if (int rc = bind(*cx)) return rc;
+        {
+            std::lock_guard<std::mutex> lk(cx->lane_mu);
+            for (auto& l : cx->lanes)
+                if (!l->busy) { (void)hipStreamSynchronize(l->st); (void)hipStreamSynchronize(l->copy_st); l->release_buffers(); }
+        }
+        std::lock_guard<std::mutex> lk(cx->mu);
+        bool any = false;
+        for (auto it = cx->tables.begin(); it != cx->tables.end();) {
+            if (it->second.use_count() == 1) {
+                if (!any) { (void)hipDeviceSynchronize(); any = true; }
+                it = cx->tables.erase(it);
+            } else ++it;
+        }
     }
-    std::lock_guard<std::mutex> lk(g.mu);
-    g.tables.clear();                        // graphs still alive keep their own references
-    for (auto& kv : g.ws) kv.second->release();
-    g.ws.clear();
-    for (auto& sl : g.slots) {
-        if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
-        if (sl.st) (void)hipStreamDestroy(sl.st);
-        if (sl.cst) (void)hipStreamDestroy(sl.cst);
-        for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
-        sl.cst = nullptr;
-        (void)hipFree(sl.din); (void)hipFree(sl.dout);
-        sl.ws.release();
-        sl.tables.clear();
-        sl.st = nullptr; sl.din = sl.dout = nullptr; sl.din_n = sl.dout_n = 0;
-        sl.exec = nullptr; sl.gw = sl.gh = 0; sl.gmode = -1; sl.uses = 0;
-    }
-    g.ready = false;
+    return SRCNN_OK;
 }
 
 int srcnn_set_mode(int mode)
 {
     if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST && mode != SRCNN_MODE_FAST_F16) return fail(SRCNN_E_ARG, "bad mode %d", mode);
-    return g.mode.exchange(mode);
+    return G.mode.exchange(mode);
 }
 
-int srcnn_get_mode(void) { return g.mode.load(); }
+int srcnn_get_mode(void) { return G.mode.load(); }
 
 size_t srcnn_set_workspace_limit(size_t bytes)
 {
-    return g.ws_budget.exchange(std::max<size_t>(bytes, 1u << 20));
+    return G.ws_budget.exchange(std::max<size_t>(bytes, 1u << 20));
 }
 
 int srcnn_device_name(char* buf, size_t cap)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
+    Ctx* cx = cur_ctx();
+    if (!cx) return SRCNN_E_NODEVICE;
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
+    HIP_TRY(hipGetDeviceProperties(&prop, cx->device));
     snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return SRCNN_OK;
 }
 
-// ---- plumbing ----------------------------------------------------------------------------------
+// ---- plumbing (all on the calling thread's current context) ------------------------------------
 void* srcnn_dev_alloc(size_t bytes)
 {
-    if (ensure_init()) return nullptr;
+    if (!cur_ctx()) return nullptr;
     void* p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fail(SRCNN_E_DEVMEM, "hipMalloc(%zu) failed", bytes); return nullptr; }
     return p;
@@ -743,65 +923,84 @@ void* srcnn_dev_alloc(size_t bytes)
 void srcnn_dev_free(void* p) { if (p) (void)hipFree(p); }
 void* srcnn_host_alloc_pinned(size_t bytes)
 {
-    if (ensure_init()) return nullptr;
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(SRCNN_E_DEVMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
-    return p;
+    Ctx* cx = cur_ctx();
+    if (!cx) return nullptr;
+    return pinned_alloc(*cx, bytes);
 }
 void srcnn_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 
 int srcnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
     if (stream) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     else HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return SRCNN_OK;
 }
 int srcnn_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
     if (stream) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     else HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return SRCNN_OK;
 }
 int srcnn_memset_dev(void* dst, int byte, size_t bytes, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
     HIP_TRY(hipMemsetAsync(dst, byte, bytes, (hipStream_t)stream));
     return SRCNN_OK;
 }
 int srcnn_stream_create(void** stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    Ctx* cx = cur_ctx();
+    if (!cx) return SRCNN_E_NODEVICE;
     hipStream_t s;
     HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    { std::lock_guard<std::mutex> lk(G.mu); G.stream_ctx[s] = cx->index; }
     *stream = s;
     return SRCNN_OK;
 }
 int srcnn_stream_destroy(void* stream)
 {
     if (!stream) return SRCNN_OK;
+    Ctx* cx = ctx_for_stream(stream);
+    if (!cx) return SRCNN_E_NODEVICE;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     std::unique_ptr<Workspace> ws;
     {
-        std::lock_guard<std::mutex> lk(g.mu);
-        auto it = g.ws.find((hipStream_t)stream);
-        if (it != g.ws.end()) { ws = std::move(it->second); g.ws.erase(it); }
+        std::lock_guard<std::mutex> lk(cx->mu);
+        auto it = cx->ws.find((hipStream_t)stream);
+        if (it != cx->ws.end()) { ws = std::move(it->second); cx->ws.erase(it); }
     }
     if (ws) { std::lock_guard<std::mutex> wl(ws->mu); ws->release(); }
+    { std::lock_guard<std::mutex> lk(G.mu); G.stream_ctx.erase((hipStream_t)stream); }
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return SRCNN_OK;
 }
-int srcnn_stream_sync(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return SRCNN_OK; }
-int srcnn_device_sync(void) { int rc = ensure_init(); if (rc) return rc; HIP_TRY(hipDeviceSynchronize()); return SRCNN_OK; }
+int srcnn_stream_sync(void* stream)
+{
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return SRCNN_OK;
+}
+int srcnn_device_sync(void) { if (!cur_ctx()) return SRCNN_E_NODEVICE; HIP_TRY(hipDeviceSynchronize()); return SRCNN_OK; }
 int srcnn_event_create(void** ev)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    if (!cur_ctx()) return SRCNN_E_NODEVICE;
     hipEvent_t e; HIP_TRY(hipEventCreate(&e)); *ev = e; return SRCNN_OK;
 }
 int srcnn_event_destroy(void* ev) { if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev)); return SRCNN_OK; }
-int srcnn_event_record(void* ev, void* stream) { HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return SRCNN_OK; }
-int srcnn_stream_wait_event(void* stream, void* ev) { HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return SRCNN_OK; }
+int srcnn_event_record(void* ev, void* stream)
+{
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return SRCNN_OK;
+}
+int srcnn_stream_wait_event(void* stream, void* ev)
+{
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    return SRCNN_OK;
+}
 int srcnn_event_elapsed_ms(void* start, void* stop, float* ms)
 {
     HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
@@ -813,9 +1012,10 @@ int srcnn_event_elapsed_ms(void* start, void* stop, float* ms)
 int srcnn_y_path_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
                          float* d_out, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_y_path_args(d_in, w, h, dw, dh, filter, d_out))) return rc;
     StreamCall sc(stream);
+    if (sc.rc) return sc.rc;
     return y_path_frame(sc.c, d_in, w, h, dw, dh, filter, d_out);
 }
 
@@ -824,38 +1024,16 @@ int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* 
     return srcnn_y_path_f32_dev(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out, stream);
 }
 
-namespace {
-int batch_frames(Call& c, const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out)
-{
-    const size_t in_n = (size_t)w * h, out_n = in_n * 4;
-    for (unsigned f = 0; f < nframes; ++f) {
-        int rc = y_path_frame(c, d_in + f * in_n, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out + f * out_n);
-        if (rc) return rc;
-    }
-    return SRCNN_OK;
-}
-}  // namespace
-
 int srcnn_y_upscale2x_f32_batch_dev(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out,
                                     void* stream)
 {
     if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_y_path_args(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out))) return rc;
     StreamCall sc(stream);
+    if (sc.rc) return sc.rc;
     return batch_frames(sc.c, d_in, w, h, nframes, d_out);
 }
-
-namespace {
-// A captured batch owns everything its kernel nodes point at: its scratch and its contribution tables live exactly
-// as long as the handle, whatever happens to the stream's own workspace or to the table cache in the meantime.
-struct BatchGraph {
-    hipGraphExec_t exec = nullptr;
-    hipStream_t stream = nullptr;
-    Workspace ws;
-    std::vector<TableRef> tables;
-};
-}  // namespace
 
 int srcnn_batch_graph_create(const float* d_in, unsigned w, unsigned h, unsigned nframes, float* d_out, void* stream,
                              void** graph)
@@ -863,12 +1041,15 @@ int srcnn_batch_graph_create(const float* d_in, unsigned w, unsigned h, unsigned
     if (!graph) return fail(SRCNN_E_ARG, "graph == NULL");
     if (!stream) return fail(SRCNN_E_ARG, "graph capture needs a non-default stream");
     if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_y_path_args(d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, d_out))) return rc;
+    Ctx* cx = ctx_for_stream(stream);
+    if (!cx) return SRCNN_E_NODEVICE;
     auto bg = std::make_unique<BatchGraph>();
+    bg->cx = cx;
     bg->stream = (hipStream_t)stream;
     Call c;
-    c.s = bg->stream; c.ws = &bg->ws; c.mode = g.mode.load(); c.hold = &bg->tables;
+    c.cx = cx; c.s = bg->stream; c.ws = &bg->ws; c.mode = G.mode.load(); c.hold = &bg->tables;
     auto drop = [&](int code) { (void)hipStreamSynchronize(bg->stream); bg->ws.release(); return code; };
     // eager run first: builds tables and grows the private workspace, so nothing allocates inside the capture
     if ((rc = batch_frames(c, d_in, w, h, nframes, d_out))) return drop(rc);
@@ -895,6 +1076,7 @@ int srcnn_batch_graph_launch(void* graph)
 {
     if (!graph) return fail(SRCNN_E_ARG, "graph == NULL");
     BatchGraph* b = static_cast<BatchGraph*>(graph);
+    if (int rc = bind(*b->cx)) return rc;
     HIP_TRY(hipGraphLaunch(b->exec, b->stream));
     return SRCNN_OK;
 }
@@ -903,6 +1085,7 @@ int srcnn_batch_graph_destroy(void* graph)
 {
     if (!graph) return SRCNN_OK;
     BatchGraph* b = static_cast<BatchGraph*>(graph);
+    (void)hipSetDevice(b->cx->device);
     (void)hipStreamSynchronize(b->stream);
     (void)hipGraphExecDestroy(b->exec);
     b->ws.release();
@@ -913,32 +1096,47 @@ int srcnn_batch_graph_destroy(void* graph)
 int srcnn_y_upscale2x_f32_band_dev(const float* d_in, unsigned w, unsigned h, unsigned row0, unsigned rows,
                                    float* d_out_band, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_plane(d_in, w, h, d_out_band))) return rc;
     if (rows == 0) return fail(SRCNN_E_ARG, "rows == 0");
     if ((unsigned long long)row0 + rows > 2ull * h) return fail(SRCNN_E_ARG, "band [%u,+%u) outside the %u output rows", row0, rows, 2 * h);
     StreamCall sc(stream);
+    if (sc.rc) return sc.rc;
     return y_path_range(sc.c, d_in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, row0, row0 + rows, d_out_band);
 }
 
 // ---- per-kernel timing -------------------------------------------------------------------------
-int srcnn_profile_enable(int on) { return g.profiling.exchange(on != 0) ? 1 : 0; }
+int srcnn_profile_enable(int on) { return G.profiling.exchange(on != 0) ? 1 : 0; }
 
 int srcnn_profile_reset(void)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    drain_spans_locked();
-    for (int i = 0; i < SRCNN_STAGE_COUNT; ++i) { g.stage_ms[i] = 0; g.stage_n[i] = 0; }
+    for (int k = 0; k < context_count(); ++k) {
+        Ctx* cx = context_at(k);
+        if (!cx) continue;
+        (void)hipSetDevice(cx->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        drain_spans_locked(*cx);
+        for (int i = 0; i < SRCNN_STAGE_COUNT; ++i) { cx->stage_ms[i] = 0; cx->stage_n[i] = 0; }
+    }
+    if (Ctx* cx = context_at(srcnn_get_context())) (void)hipSetDevice(cx->device);
     return SRCNN_OK;
 }
 
 int srcnn_profile_read(int stage, double* total_ms, unsigned long long* launches)
 {
     if (stage < 0 || stage >= SRCNN_STAGE_COUNT) return fail(SRCNN_E_ARG, "bad stage %d", stage);
-    std::lock_guard<std::mutex> lk(g.mu);
-    drain_spans_locked();
-    if (total_ms) *total_ms = g.stage_ms[stage];
-    if (launches) *launches = g.stage_n[stage];
+    double ms = 0; unsigned long long n = 0;
+    for (int k = 0; k < context_count(); ++k) {            // summed over the contexts of the process
+        Ctx* cx = context_at(k);
+        if (!cx) continue;
+        (void)hipSetDevice(cx->device);
+        std::lock_guard<std::mutex> lk(cx->mu);
+        drain_spans_locked(*cx);
+        ms += cx->stage_ms[stage]; n += cx->stage_n[stage];
+    }
+    if (Ctx* cx = context_at(srcnn_get_context())) (void)hipSetDevice(cx->device);
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
     return SRCNN_OK;
 }
 
@@ -946,10 +1144,11 @@ int srcnn_profile_read(int stage, double* total_ms, unsigned long long* launches
 int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
                            float* d_out, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_y_path_args(d_in, w, h, dw, dh, filter, d_out))) return rc;
     if (dh > (1u << 20) || h > (1u << 20)) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
     StreamCall sc(stream);
+    if (sc.rc) return sc.rc;
     rc = resample_rows_range(sc.c, d_in, w, h, dw, dh, filter, 0, dh, d_out);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -958,9 +1157,10 @@ int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned d
 
 int srcnn_conv1_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c1, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_plane(d_y, w, h, d_c1))) return rc;
     if (h > 65535u * 4u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
     launch_conv1_planes(d_y, (int)w, (int)h, d_c1, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
@@ -968,8 +1168,9 @@ int srcnn_conv1_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c1, v
 
 int srcnn_conv2_f32_dev(const float* d_c1, unsigned w, unsigned h, float* d_c2, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_plane(d_c1, w, h, d_c2))) return rc;
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
     launch_conv2_planes(d_c1, (size_t)w * h, d_c2, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
@@ -977,10 +1178,11 @@ int srcnn_conv2_f32_dev(const float* d_c1, unsigned w, unsigned h, float* d_c2, 
 
 int srcnn_conv3_f32_dev(const float* d_c2, unsigned w, unsigned h, float* d_out, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_plane(d_c2, w, h, d_out))) return rc;
     if (h > 65535u * 16u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
-    launch_conv3(d_c2, (size_t)w * h, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, g.mode.load() == SRCNN_MODE_STRICT,
+    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
+    launch_conv3(d_c2, (size_t)w * h, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, G.mode.load() == SRCNN_MODE_STRICT,
                  (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
@@ -988,303 +1190,15 @@ int srcnn_conv3_f32_dev(const float* d_c2, unsigned w, unsigned h, float* d_out,
 
 int srcnn_conv12_f32_dev(const float* d_y, unsigned w, unsigned h, float* d_c2, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_plane(d_y, w, h, d_c2))) return rc;
     if (h > 65535u * 4u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
     Call c;
-    c.s = (hipStream_t)stream; c.mode = g.mode.load();
+    c.cx = ctx_for_stream(stream);
+    if (!c.cx) return SRCNN_E_NODEVICE;
+    c.s = (hipStream_t)stream; c.mode = G.mode.load();
     run_conv12(c, d_y, (int)w, (int)h, 0, (int)h, d_c2, (size_t)w * h, 0, (int)h);
     HIP_TRY(hipGetLastError());
-    return SRCNN_OK;
-}
-
-// ---- host-pointer conveniences -----------------------------------------------------------------
-int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* out)
-{
-    int rc = ensure_init(); if (rc) return rc;
-    if ((rc = check_plane(in, w, h, out))) return rc;
-    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
-    float *d_in = nullptr, *d_out = nullptr;
-    const size_t in_b = sizeof(float) * (size_t)w * h, out_b = sizeof(float) * (size_t)dw * dh;
-    if (hipMalloc((void**)&d_in, in_b) != hipSuccess || hipMalloc((void**)&d_out, out_b) != hipSuccess) {
-        hipFree(d_in);
-        return fail(SRCNN_E_DEVMEM, "device allocation of %zu+%zu bytes failed", in_b, out_b);
-    }
-    rc = SRCNN_OK;
-    if (hipMemcpy(d_in, in, in_b, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SRCNN_E_HIP, "H2D copy failed");
-    if (!rc) rc = srcnn_y_path_f32_dev(d_in, w, h, dw, dh, filter, d_out, nullptr);
-    if (!rc && hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SRCNN_E_HIP, "D2H copy failed");
-    hipFree(d_in); hipFree(d_out);
-    return rc;
-}
-
-int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out)
-{
-    return srcnn_y_path_f32(in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, out);
-}
-
-int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph)
-{
-    int rc = ensure_init(); if (rc) return rc;
-    if ((rc = check_plane(in, w, h, out))) return rc;
-    if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
-    const size_t in_n = (size_t)w * h, out_n = in_n * 4;
-    const size_t in_b = in_n * sizeof(float), out_b = out_n * sizeof(float);
-    const int mode = g.mode.load();
-
-    // page-lock the caller's frames so the copies are truly asynchronous -- unless they already are (buffers from
-    // srcnn_host_alloc_pinned / hipHostMalloc: registering a gigabyte again costs milliseconds per call); harmless if it fails
-    auto pinned = [](const void* p) {
-        hipPointerAttribute_t a;
-        const bool yes = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
-        (void)hipGetLastError();
-        return yes;
-    };
-    const bool reg_in = !pinned(in) && hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterDefault) == hipSuccess;
-    const bool reg_out = !pinned(out) && hipHostRegister(out, out_b * nframes, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
-
-    std::lock_guard<std::mutex> slk(g.stream_mu);
-    const int nslots = nframes > 1 ? 2 : 1;
-    for (int i = 0; i < nslots && !rc; ++i) {
-        StreamSlot& sl = g.slots[i];
-        if (!sl.st && hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
-        if (!rc && !sl.cst && hipStreamCreateWithFlags(&sl.cst, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
-        for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out})
-            if (!rc && !*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = fail(SRCNN_E_HIP, "event create");
-        if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) {     // shape or mode changed: drop the graph first,
-            if (sl.exec) { (void)hipStreamSynchronize(g.slots[0].st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
-            sl.ws.frozen = false;                                          // then its buffers may move again
-            sl.tables.clear();
-            sl.gw = w; sl.gh = h; sl.gmode = mode; sl.uses = 0;
-        }
-        if (!rc) rc = grow(sl.din, sl.din_n, in_n);
-        if (!rc) rc = grow(sl.dout, sl.dout_n, out_n);
-    }
-    // Pipeline.  Copies run on the slots' copy-only streams and every copy/kernel dependency that involves a copy is
-    // resolved on the HOST: a copy that has to wait on another queue's event device-side does not overlap the other
-    // slot's kernels on this runtime (measured with tools/hs_probe.py, 4K frames: 12.2-12.4 ms per frame with the D2H on
-    // the kernel stream or behind hipStreamWaitEvent, 10.8 ms when the host waits for the kernels and then queues the
-    // copy on an idle stream).  So a copier thread waits for frame f's kernels and then issues its D2H; the main thread
-    // waits for the slot's previous D2H before it reuses the slot.
-    const int dev = g.device;
-    std::atomic<unsigned> launched{0};     // frames whose kernels have been queued (e_k recorded)
-    std::atomic<unsigned> copied{0};       // frames whose D2H has been queued (e_out recorded)
-    std::atomic<int> abort_copy{0}, copy_err{0};
-    std::thread copier([&] {
-        (void)hipSetDevice(dev);
-        for (unsigned f = 0; f < nframes; ++f) {
-            while (launched.load(std::memory_order_acquire) <= f) {
-                if (abort_copy.load(std::memory_order_acquire)) return;
-                std::this_thread::yield();
-            }
-            StreamSlot& sl = g.slots[f % nslots];
-            if (hipEventSynchronize(sl.e_k) != hipSuccess ||
-                hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.cst) != hipSuccess ||
-                hipEventRecord(sl.e_out, sl.cst) != hipSuccess) copy_err = 1;
-            copied.store(f + 1, std::memory_order_release);
-        }
-    });
-    hipStream_t ks = g.slots[0].st;        // ALL kernels go to one stream: frames back to back, never two frames' kernels
-                                           // sharing the chip (that costs more than it overlaps: the persistent layer-1+2
-                                           // kernel partitions its tiles over the workgroups it expects to be resident)
-    for (unsigned f = 0; f < nframes && !rc; ++f) {
-        StreamSlot& sl = g.slots[f % nslots];
-        Call c;
-        c.s = ks; c.ws = &sl.ws; c.mode = mode; c.hold = &sl.tables;
-        if (f >= (unsigned)nslots) {
-            // the slot's previous frame: its kernels are done (the copier saw e_k) once its D2H has been queued; wait for
-            // that D2H to finish before din / dout are reused
-            while (copied.load(std::memory_order_acquire) < f - nslots + 1) std::this_thread::yield();
-            if (hipEventSynchronize(sl.e_out) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
-        }
-        // frame in: also resolved on the host (the previous frame's kernels keep the device busy meanwhile)
-        if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.cst) != hipSuccess ||
-            hipEventRecord(sl.e_in, sl.cst) != hipSuccess || hipEventSynchronize(sl.e_in) != hipSuccess) {
-            rc = fail(SRCNN_E_HIP, "H2D"); break;
-        }
-        if (use_graph && sl.uses >= 1 && !sl.exec) {
-            // The slot has run this shape eagerly once: tables and workspaces exist, so the kernel sequence
-            // can be captured without any allocation inside the capture.
-            hipGraph_t graph = nullptr;
-            sl.ws.frozen = true;
-            c.timing = false;              // event pairs cannot be timed inside a capture
-            if (hipStreamBeginCapture(ks, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
-            if (!rc) rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
-            if (hipStreamEndCapture(ks, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
-            c.timing = true;
-            if (!rc && hipGraphInstantiate(&sl.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(SRCNN_E_HIP, "graph instantiate");
-            if (graph) (void)hipGraphDestroy(graph);
-            if (rc) { sl.ws.frozen = false; break; }
-        }
-        if (use_graph && sl.exec) {
-            if (hipGraphLaunch(sl.exec, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
-        } else {
-            if (sl.tables.size() > 16) sl.tables.clear();   // eager runs re-take their references every frame
-            rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
-            if (rc) break;
-        }
-        if (hipEventRecord(sl.e_k, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "event record"); break; }
-        launched.store(f + 1, std::memory_order_release);
-        ++sl.uses;
-    }
-    if (rc) abort_copy.store(1, std::memory_order_release);     // the copier stops at the first frame that was never launched
-    copier.join();
-    for (int i = 0; i < nslots; ++i) {
-        if (g.slots[i].st) (void)hipStreamSynchronize(g.slots[i].st);
-        if (g.slots[i].cst) (void)hipStreamSynchronize(g.slots[i].cst);
-    }
-    if (!rc && copy_err) rc = fail(SRCNN_E_HIP, "a device-to-host copy of the frame stream failed");
-    if (reg_in) (void)hipHostUnregister(const_cast<float*>(in));
-    if (reg_out) (void)hipHostUnregister(out);
-    return rc;
-}
-
-int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigned nframes, float* out)
-{
-    return srcnn_y_upscale2x_f32_stream(in, w, h, nframes, out, 0);
-}
-
-int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
-                     unsigned char* out, unsigned char* conv_opt)
-{
-    if (!rgb || !out || w == 0 || h == 0 || d == 0) return fail(SRCNN_E_ARG, "NULL pointer or zero dimension");
-    if (d != 3 && d != 4) return fail(SRCNN_E_UNSUPPORTED, "depth %u: the reference reads uninitialised planes for d<3 (src/libsrcnn.cpp:235-236)", d);
-    if ((float)w * multiply <= 0.f || (float)h * multiply <= 0.f) return fail(SRCNN_E_SCALE, "non-positive scaled size");
-    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
-    int rc = ensure_init(); if (rc) return rc;
-    const unsigned dw = (unsigned)((float)w * multiply), dh = (unsigned)((float)h * multiply);   // src/libsrcnn.cpp:662-663
-    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
-    if ((unsigned long long)w * h > 0x7fffffffULL || (unsigned long long)dw * dh > 0x7fffffffULL)
-        return fail(SRCNN_E_UNSUPPORTED, "plane too large");
-    const size_t n = (size_t)w * h, dn = (size_t)dw * dh;
-
-    // Everything below runs on a lane leased for this call only (see ProcLane): concurrent ProcessSRCNN calls from
-    // several host threads are independent, like the reference's.
-    LaneLease lease;
-    if (lease.rc) return lease.rc;
-    ProcLane& L = *lease.lane;
-    Workspace& ws = L.ws;
-    hipStream_t s = L.st;
-    std::vector<TableRef> tables;
-    Call c;
-    c.s = s; c.ws = &ws; c.mode = g.mode.load(); c.hold = &tables;
-
-    // planes: [Y Cb Cr A] at source size, then [Y' Cb' Cr' A'] at destination size
-    if ((rc = grow_ws(ws, ws.planes, ws.planes_n, 4 * n + 4 * dn))) return rc;
-    if ((rc = grow_ws(ws, ws.bytes, ws.bytes_n, n * d + dn * d + dn))) return rc;
-    float* sp[4]; float* dp[4];
-    for (int k = 0; k < 4; ++k) { sp[k] = ws.planes + k * n; dp[k] = ws.planes + 4 * n + k * dn; }
-    unsigned char* d_rgb = ws.bytes; unsigned char* d_out = ws.bytes + n * d; unsigned char* d_conv = d_out + dn * d;
-    const bool trace = getenv("SRCNN_TRACE") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
-    };
-    const int cfilter = (filter == SRCNN_FILTER_NEAREST) ? SRCNN_FILTER_NEAREST : SRCNN_FILTER_BILINEAR;   // src/libsrcnn.cpp:701-713
-    const size_t out_bytes = dn * d;
-
-    if (out_bytes < (8u << 20)) {
-        // small image: one shot on the lane's stream
-        HIP_TRY(hipMemcpyAsync(d_rgb, rgb, n * d, hipMemcpyHostToDevice, s));
-        launch_rgb_split(d_rgb, n, (int)d, sp[0], sp[1], sp[2], sp[3], s);
-        for (unsigned k = 1; k < d; ++k)
-            if ((rc = resample_rows_range(c, sp[k], w, h, dw, dh, cfilter, 0, dh, dp[k]))) return rc;
-        if ((rc = y_path_frame(c, sp[0], w, h, dw, dh, filter, dp[0]))) return rc;
-        launch_ycc_merge(dp[0], dp[1], dp[2], dp[3], dn, (int)d, d_out, conv_opt ? d_conv : nullptr, s);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
-        if (conv_opt) HIP_TRY(hipMemcpyAsync(conv_opt, d_conv, dn, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        return SRCNN_OK;
-    }
-
-    // Large image: the reference's only benchmark is the wall time of this call (src/test.cpp:653-672), and
-    // for a GPU that is dominated by moving ~4 B per output pixel to and from pageable host memory.  So:
-    // page-locked staging on both sides, the output produced in horizontal bands (bit-identical to the whole
-    // frame, tests/test_gpu_parity.py::test_bands_equal_whole_frame), each band's D2H on a copy stream while the
-    // next band computes, and a helper thread that fans each landed band out to the caller's buffers.
-    const auto t0 = now();
-    if ((rc = grow_pinned(L.pin_in, L.pin_in_n, n * d))) return rc;
-    if ((rc = grow_pinned(L.pin_out, L.pin_out_n, out_bytes + dn))) return rc;
-    const unsigned nb = std::max(1u, std::min(8u, dh / 256u));
-    while (L.band_events.size() < 2 * nb) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        L.band_events.push_back(e);
-    }
-    parallel_memcpy(L.pin_in, rgb, n * d);
-    HIP_TRY(hipMemcpyAsync(d_rgb, L.pin_in, n * d, hipMemcpyHostToDevice, s));
-    launch_rgb_split(d_rgb, n, (int)d, sp[0], sp[1], sp[2], sp[3], s);
-    for (unsigned k = 1; k < d; ++k)
-        if ((rc = resample_rows_range(c, sp[k], w, h, dw, dh, cfilter, 0, dh, dp[k]))) return rc;
-    const auto t1 = now();
-
-    unsigned char* pin_rgb = L.pin_out;
-    unsigned char* pin_conv = L.pin_out + out_bytes;
-    std::vector<unsigned> r0s(nb + 1);
-    unsigned max_band = 0;
-    for (unsigned b = 0; b <= nb; ++b) r0s[b] = (unsigned)((unsigned long long)dh * b / nb);
-    for (unsigned b = 0; b < nb; ++b) max_band = std::max(max_band, r0s[b + 1] - r0s[b]);
-    // size the band scratch once, for the largest band plus its halos, so no band re-allocates mid-pipeline
-    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !g.f16_unfused;           // the fused kernel has no layer-2 planes
-    if (!no_planes && (rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
-    if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * std::min(dh, max_band + 12)))) return rc;
-    if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
-    const int dev = g.device;
-    std::atomic<int> copy_err{0};
-    std::atomic<unsigned> enqueued{0};      // bands whose kernels have been queued (their "computed" event recorded) in THIS call
-    std::atomic<int> abort_bands{0};
-    // The helper resolves the copy dependencies on the HOST: it waits for a band's kernels, then queues the band's D2H on
-    // the idle copy stream (a copy that waits device-side on the kernel stream's event does not run beside the next band's
-    // kernels on this runtime, profiles/r02_stream_overlap.txt), and fans the previous band out to the caller's buffers
-    // while that copy is in flight.
-    std::thread fanout([&] {
-        (void)hipSetDevice(dev);
-        auto fan = [&](unsigned b) {
-            if (hipEventSynchronize(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
-            const size_t p0 = (size_t)r0s[b] * dw, p1 = (size_t)r0s[b + 1] * dw;
-            parallel_memcpy(out + p0 * d, pin_rgb + p0 * d, (p1 - p0) * d);
-            if (conv_opt) parallel_memcpy(conv_opt + p0, pin_conv + p0, p1 - p0);
-        };
-        unsigned done = 0;
-        for (unsigned b = 0; b < nb; ++b) {
-            while (enqueued.load(std::memory_order_acquire) <= b) {
-                if (abort_bands.load(std::memory_order_acquire)) return;
-                std::this_thread::yield();
-            }
-            const size_t p0 = (size_t)r0s[b] * dw, pn = (size_t)(r0s[b + 1] - r0s[b]) * dw;
-            if (hipEventSynchronize(L.band_events[2 * b]) != hipSuccess ||
-                hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
-                (conv_opt && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess) ||
-                hipEventRecord(L.band_events[2 * b + 1], L.copy_st) != hipSuccess) { copy_err = 1; return; }
-            if (b > 0) fan(b - 1);
-            done = b;
-        }
-        fan(done);
-    });
-    int launch_rc = SRCNN_OK;
-    for (unsigned b = 0; b < nb; ++b) {
-        const unsigned r0 = r0s[b], r1 = r0s[b + 1];
-        const size_t p0 = (size_t)r0 * dw, pn = (size_t)(r1 - r0) * dw;
-        launch_rc = y_path_rows(c, sp[0], w, h, dw, dh, filter, r0, r1, dp[0] + p0);
-        if (!launch_rc) {
-            launch_ycc_merge(dp[0] + p0, dp[1] + p0, dp[2] + p0, dp[3] + p0, pn, (int)d, d_out + p0 * d,
-                             conv_opt ? d_conv + p0 : nullptr, s);
-            if (hipEventRecord(L.band_events[2 * b], s) != hipSuccess) launch_rc = fail(SRCNN_E_HIP, "band %u event record failed", b);
-        }
-        if (launch_rc) { abort_bands.store(1, std::memory_order_release); break; }
-        enqueued.store(b + 1, std::memory_order_release);
-    }
-    fanout.join();
-    const auto t2 = now();
-    hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(L.copy_st);
-    if (launch_rc) return launch_rc;
-    if (e1 != hipSuccess || e2 != hipSuccess || copy_err) return fail(SRCNN_E_HIP, "pipeline failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-    HIP_TRY(hipGetLastError());
-    if (trace)
-        fprintf(stderr, "srcnn_process_u8 %ux%ux%u x%.2f: stage-in+chroma %.2f ms, %u bands (compute || D2H || fan-out) %.2f ms\n",
-                w, h, d, (double)multiply, ms(t0, t1), nb, ms(t1, t2));
     return SRCNN_OK;
 }
 
@@ -1302,18 +1216,27 @@ int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, 
 // of workgroup 0 written to d_dbg (8 waves x 64 rows x 4 stamps: row start, layer 1 done, layers 2+3 done, row done).
 int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, unsigned long long* d_dbg, void* stream)
 {
-    int rc = ensure_init(); if (rc) return rc;
+    int rc;
     if ((rc = check_plane(d_up, w, h, d_out))) return rc;
-    launch_fused_f16(d_up, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, g.fused_w, g.num_cus, (hipStream_t)stream, d_dbg);
+    Ctx* cx = ctx_for_stream(stream);
+    if (!cx) return SRCNN_E_NODEVICE;
+    launch_fused_f16(d_up, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, cx->fused_w, cx->num_cus, (hipStream_t)stream, d_dbg);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }
 
-// test hook: number of cached contribution tables / of ProcessSRCNN lanes created so far
+// test hook: number of cached contribution tables / of ProcessSRCNN lanes created so far, summed over the contexts
 int srcnn_debug_counts(int* tables, int* lanes)
 {
-    { std::lock_guard<std::mutex> lk(g.mu); if (tables) *tables = (int)g.tables.size(); }
-    { std::lock_guard<std::mutex> lk(g.lane_mu); if (lanes) *lanes = (int)g.lanes.size(); }
+    int nt = 0, nl = 0;
+    for (int k = 0; k < context_count(); ++k) {
+        Ctx* cx = context_at(k);
+        if (!cx) continue;
+        { std::lock_guard<std::mutex> lk(cx->mu); nt += (int)cx->tables.size(); }
+        { std::lock_guard<std::mutex> lk(cx->lane_mu); nl += (int)cx->lanes.size(); }
+    }
+    if (tables) *tables = nt;
+    if (lanes) *lanes = nl;
     return SRCNN_OK;
 }
 

@@ -8,14 +8,16 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/srcnn_amd.h"
 
-namespace srcnn { void set_last_error(const char* msg); }
+#include "srcnn_host.hpp"
 
 namespace {
 
@@ -38,8 +40,21 @@ struct Rccl {
 Rccl R;
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_nranks = 1;
+int g_device = 0;                       // the device the communicator is bound to
 float* g_token = nullptr;
+hipStream_t g_comm_stream = nullptr;    // the tiled path's gathers run here, beside the compute stream
+std::vector<hipEvent_t> g_events;       // sub-band "kernels queued" events + one "gathers done" event
 std::mutex g_mu;
+
+// A consistent view of the communicator for one call (taken under g_mu; the collective itself runs outside it so that a
+// rank blocked in RCCL never blocks srcnn_comm_rank on another thread).
+struct CommView { ncclComm_t comm; int rank, nranks, device; };
+bool view(CommView& v)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    v = CommView{g_comm, g_rank, g_nranks, g_device};
+    return v.comm != nullptr;
+}
 thread_local char g_cerr[256];
 
 int load()
@@ -110,6 +125,7 @@ extern "C" {
 
 int srcnn_comm_unique_id(unsigned char id[SRCNN_COMM_ID_BYTES])
 {
+    if (!srcnn::cur_ctx()) return SRCNN_E_NODEVICE;
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = load()) return rc;
     ncclUniqueId u;
@@ -120,6 +136,10 @@ int srcnn_comm_unique_id(unsigned char id[SRCNN_COMM_ID_BYTES])
 
 int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int nranks)
 {
+    // bind the calling thread to the current context's device first: a helper thread that never touched HIP would
+    // otherwise create the communicator on device 0
+    srcnn::Ctx* cx = srcnn::cur_ctx();
+    if (!cx) return SRCNN_E_NODEVICE;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_comm) return comm_fail("srcnn_comm_init: communicator already initialised");
     if (!id || rank < 0 || nranks <= 0 || rank >= nranks) return comm_fail("srcnn_comm_init: bad rank / nranks / id");
@@ -136,7 +156,7 @@ int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int n
         return SRCNN_E_DEVMEM;
     }
     g_comm = comm; g_token = token;
-    g_rank = rank; g_nranks = nranks;
+    g_rank = rank; g_nranks = nranks; g_device = cx->device;
     return SRCNN_OK;
 }
 
@@ -144,46 +164,49 @@ int srcnn_comm_destroy(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_comm) return SRCNN_OK;
+    (void)hipSetDevice(g_device);
     hipDeviceSynchronize();
     R.CommDestroy(g_comm);
     g_comm = nullptr;
     hipFree(g_token); g_token = nullptr;
+    for (auto e : g_events) (void)hipEventDestroy(e);
+    g_events.clear();
+    if (g_comm_stream) (void)hipStreamDestroy(g_comm_stream);
+    g_comm_stream = nullptr;
     g_rank = 0; g_nranks = 1;
     return SRCNN_OK;
 }
 
 int srcnn_comm_rank(int* rank, int* nranks)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_comm) return comm_fail("no communicator");
-    if (rank) *rank = g_rank;
-    if (nranks) *nranks = g_nranks;
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    if (rank) *rank = v.rank;
+    if (nranks) *nranks = v.nranks;
     return SRCNN_OK;
 }
 
-// counts[r] floats from rank r land at d_recv + sum(counts[0..r)) on the root: bands of unequal height (an
-// output height that the rank count does not divide) assemble into one contiguous frame.
-int srcnn_comm_gatherv_f32(const float* d_send, const size_t* counts, float* d_recv, int root, void* stream)
+// counts[r] floats from rank r land at d_recv + offsets[r] on the root.  counts / offsets must be identical on every rank
+// (a mismatch would hang in GroupEnd; the callers in this library derive them from (height, nranks) alone).
+int srcnn_comm_gatherv_at_f32(const float* d_send, const size_t* counts, const size_t* offsets, float* d_recv, int root,
+                              void* stream)
 {
-    if (!g_comm) return comm_fail("no communicator");
-    if (!counts || root < 0 || root >= g_nranks) return comm_fail("srcnn_comm_gatherv_f32: bad counts / root");
-    if (counts[g_rank] && !d_send) return comm_fail("srcnn_comm_gatherv_f32: d_send == NULL");
-    if (g_rank == root && !d_recv) return comm_fail("srcnn_comm_gatherv_f32: d_recv == NULL on the root");
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    if (!counts || !offsets || root < 0 || root >= v.nranks) return comm_fail("srcnn_comm_gatherv_at_f32: bad counts / offsets / root");
+    if (counts[v.rank] && !d_send) return comm_fail("srcnn_comm_gatherv_at_f32: d_send == NULL");
+    if (v.rank == root && !d_recv) return comm_fail("srcnn_comm_gatherv_at_f32: d_recv == NULL on the root");
+    if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
     hipStream_t s = (hipStream_t)stream;
     // every Send/Recv of the group is attempted and GroupEnd always runs, so a failure never leaves the group open
     ncclResult_t first_bad = ncclSuccess;
     auto note = [&](ncclResult_t r) { if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r; };
     note(R.GroupStart());
-    size_t my_off = 0;
-    if (g_rank == root) {
-        size_t off = 0;
-        for (int r = 0; r < g_nranks; ++r) {
-            if (r == root) my_off = off;
-            else if (counts[r]) note(R.Recv(d_recv + off, counts[r], ncclFloat, r, g_comm, s));
-            off += counts[r];
-        }
-    } else if (counts[g_rank]) {
-        note(R.Send(d_send, counts[g_rank], ncclFloat, root, g_comm, s));
+    if (v.rank == root) {
+        for (int r = 0; r < v.nranks; ++r)
+            if (r != root && counts[r]) note(R.Recv(d_recv + offsets[r], counts[r], ncclFloat, r, v.comm, s));
+    } else if (counts[v.rank]) {
+        note(R.Send(d_send, counts[v.rank], ncclFloat, root, v.comm, s));
     }
     note(R.GroupEnd());
     if (first_bad != ncclSuccess) {
@@ -191,8 +214,8 @@ int srcnn_comm_gatherv_f32(const float* d_send, const size_t* counts, float* d_r
         srcnn::set_last_error(g_cerr);
         return SRCNN_E_COMM;
     }
-    if (g_rank == root && counts[root] && d_recv + my_off != d_send) {
-        if (hipMemcpyAsync(d_recv + my_off, d_send, counts[root] * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    if (v.rank == root && counts[root] && d_recv + offsets[root] != d_send) {
+        if (hipMemcpyAsync(d_recv + offsets[root], d_send, counts[root] * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
             srcnn::set_last_error("band gather: root's own copy failed");
             return SRCNN_E_HIP;
         }
@@ -200,26 +223,103 @@ int srcnn_comm_gatherv_f32(const float* d_send, const size_t* counts, float* d_r
     return SRCNN_OK;
 }
 
+// counts[r] floats from rank r land at d_recv + sum(counts[0..r)) on the root: bands of unequal height (an
+// output height that the rank count does not divide) assemble into one contiguous frame.
+int srcnn_comm_gatherv_f32(const float* d_send, const size_t* counts, float* d_recv, int root, void* stream)
+{
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    if (!counts) return comm_fail("srcnn_comm_gatherv_f32: bad counts / root");
+    std::vector<size_t> offs((size_t)v.nranks);
+    size_t pos = 0;
+    for (int r = 0; r < v.nranks; ++r) { offs[r] = pos; pos += counts[r]; }
+    return srcnn_comm_gatherv_at_f32(d_send, counts, offs.data(), d_recv, root, stream);
+}
+
 int srcnn_comm_gather_f32(const float* d_send, size_t count, float* d_recv, int root, void* stream)
 {
-    if (!g_comm) return comm_fail("no communicator");
-    size_t counts[1024];
-    if (g_nranks > 1024) return comm_fail("too many ranks");
-    for (int r = 0; r < g_nranks; ++r) counts[r] = count;
-    return srcnn_comm_gatherv_f32(d_send, counts, d_recv, root, stream);
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    std::vector<size_t> counts((size_t)v.nranks, count);
+    return srcnn_comm_gatherv_f32(d_send, counts.data(), d_recv, root, stream);
+}
+
+int srcnn_band_rows(unsigned out_h, int rank, int nranks, unsigned* row0, unsigned* rows)
+{
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return comm_fail("srcnn_band_rows: bad rank / nranks");
+    const unsigned base = out_h / (unsigned)nranks, rem = out_h % (unsigned)nranks;
+    if (rows) *rows = base + ((unsigned)rank < rem ? 1u : 0u);
+    if (row0) *row0 = (unsigned)rank * base + std::min((unsigned)rank, rem);
+    return SRCNN_OK;
+}
+
+int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_band, float* d_full, int root,
+                                         int sub_bands, void* stream)
+{
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    if (!d_in || w == 0 || h == 0) return comm_fail("srcnn_comm_tiled: NULL pointer or zero dimension");
+    if (root < 0 || root >= v.nranks) return comm_fail("srcnn_comm_tiled: bad root");
+    if (v.rank == root && !d_full) return comm_fail("srcnn_comm_tiled: d_full == NULL on the root");
+    if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
+    const unsigned dw = 2 * w, dh = 2 * h;
+    const unsigned nsub = (unsigned)std::max(1, std::min(sub_bands <= 0 ? 4 : sub_bands, 16));
+    hipStream_t s = (hipStream_t)stream;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_comm_stream && hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking) != hipSuccess) return comm_fail("comm stream");
+        while (g_events.size() < nsub + 2) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return comm_fail("event create");
+            g_events.push_back(e);
+        }
+    }
+    // piece i of rank r: rows [row0_r + rows_r*i/nsub, row0_r + rows_r*(i+1)/nsub) -- every rank computes the same table
+    std::vector<unsigned> row0((size_t)v.nranks), rows((size_t)v.nranks);
+    for (int r = 0; r < v.nranks; ++r) srcnn_band_rows(dh, r, v.nranks, &row0[r], &rows[r]);
+    auto cut = [&](int r, unsigned i) { return row0[r] + (unsigned)((unsigned long long)rows[r] * i / nsub); };
+    if (rows[v.rank] && !d_band) return comm_fail("srcnn_comm_tiled: d_band == NULL");
+    // the comm stream must not start before what is already queued on the caller's stream (e.g. the upload of d_in on the
+    // root, or a previous frame's use of d_full)
+    if (hipEventRecord(g_events[nsub], s) != hipSuccess || hipStreamWaitEvent(g_comm_stream, g_events[nsub], 0) != hipSuccess)
+        return comm_fail("srcnn_comm_tiled: stream hand-over failed");
+    std::vector<size_t> counts((size_t)v.nranks), offs((size_t)v.nranks);
+    for (unsigned i = 0; i < nsub; ++i) {
+        const unsigned a = cut(v.rank, i), b = cut(v.rank, i + 1);
+        float* piece = d_band ? d_band + (size_t)(a - row0[v.rank]) * dw : nullptr;
+        if (b > a) {
+            int rc = srcnn_y_upscale2x_f32_band_dev(d_in, w, h, a, b - a, piece, stream);
+            if (rc) return rc;
+        }
+        if (hipEventRecord(g_events[i], s) != hipSuccess || hipStreamWaitEvent(g_comm_stream, g_events[i], 0) != hipSuccess)
+            return comm_fail("srcnn_comm_tiled: event hand-over failed");
+        for (int r = 0; r < v.nranks; ++r) {
+            counts[r] = (size_t)(cut(r, i + 1) - cut(r, i)) * dw;
+            offs[r] = (size_t)cut(r, i) * dw;
+        }
+        int rc = srcnn_comm_gatherv_at_f32(piece, counts.data(), offs.data(), d_full, root, g_comm_stream);
+        if (rc) return rc;
+    }
+    if (hipEventRecord(g_events[nsub + 1], g_comm_stream) != hipSuccess || hipStreamWaitEvent(s, g_events[nsub + 1], 0) != hipSuccess)
+        return comm_fail("srcnn_comm_tiled: final hand-over failed");
+    return SRCNN_OK;
 }
 
 int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, void* stream)
 {
-    if (!g_comm) return comm_fail("no communicator");
-    NCCL_TRY(R.AllGather(d_send, d_recv, count, ncclFloat, g_comm, (hipStream_t)stream));
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
+    NCCL_TRY(R.AllGather(d_send, d_recv, count, ncclFloat, v.comm, (hipStream_t)stream));
     return SRCNN_OK;
 }
 
 int srcnn_comm_barrier(void* stream)
 {
-    if (!g_comm) return comm_fail("no communicator");
-    NCCL_TRY(R.AllReduce(g_token, g_token, 1, ncclFloat, ncclSum, g_comm, (hipStream_t)stream));
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
+    NCCL_TRY(R.AllReduce(g_token, g_token, 1, ncclFloat, ncclSum, v.comm, (hipStream_t)stream));
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SRCNN_E_HIP;
     return SRCNN_OK;
 }

@@ -1,0 +1,276 @@
+// srcnn_host.hpp -- host-side state shared by the C-ABI translation units (srcnn_capi.cpp: contexts, plumbing,
+// the device-resident hot path; srcnn_pipeline.cpp: the host-pointer pipelines and the node-level calls).
+// Internal; the public surface is include/srcnn_amd.h.
+//
+// One process may drive several CONTEXTS.  A context is one device binding with everything that lives in that
+// device's memory: the uploaded weights, the contribution-table cache, per-stream workspaces, the host-stream slots
+// and the ProcessSRCNN lanes.  srcnn_init(device) creates context 0 (the round-1/2 behaviour: one device per process);
+// srcnn_init_devices(list) creates one context per list entry -- the same physical device may appear several times
+// ("virtual contexts"), which is how a 1-GPU box exercises the node-level paths.  The reference's single ProcessSRCNN
+// call saturates its whole machine through OpenMP (src/libsrcnn.cpp:665,791-798,817-824); with several contexts the
+// large-image path of srcnn_process_u8 does the same with the node's GPUs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstddef>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "../../include/srcnn_amd.h"
+#include "srcnn_kernels.h"
+
+namespace srcnn {
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void set_last_error(const char* msg);
+const char* last_error();
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return ::srcnn::fail(SRCNN_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceTable {          // one uploaded AxisTable; freed only when the last reference goes
+    int* first = nullptr;
+    int* taps = nullptr;
+    double* weight = nullptr;
+    int stride = 0;
+    int max_taps = 0;
+    unsigned long long stamp = 0;      // LRU clock of the cache
+    // host copies (tiny) so that band planners can ask "which source rows does destination range [a,b) read"
+    std::vector<int> h_first, h_taps;
+    bool monotone = false;             // first[] and first[]+taps[] both non-decreasing: a tile's span is given by its ends
+    DeviceTable() = default;
+    DeviceTable(const DeviceTable&) = delete;
+    DeviceTable& operator=(const DeviceTable&) = delete;
+    ~DeviceTable() { (void)hipFree(first); (void)hipFree(taps); (void)hipFree(weight); }
+    DevAxisTable view() const { return DevAxisTable{first, taps, weight, stride, max_taps, monotone ? 1 : 0, h_first.data(), h_taps.data()}; }
+    // source index range [lo, hi) read by destination indices [a, b)
+    void source_span(unsigned a, unsigned b, unsigned& lo, unsigned& hi) const
+    {
+        int l = 0x7fffffff, h = 0;
+        for (unsigned u = a; u < b; ++u) { l = h_first[u] < l ? h_first[u] : l; const int e = h_first[u] + h_taps[u]; h = e > h ? e : h; }
+        lo = (unsigned)l; hi = (unsigned)h;
+    }
+};
+using TableRef = std::shared_ptr<DeviceTable>;
+
+struct Workspace {          // scratch of one stream / graph / lane; grow-only
+    std::mutex mu;          // held while a call enqueues work that uses this scratch
+    float* tmp = nullptr;   size_t tmp_n = 0;    // first resampler pass
+    float* up = nullptr;    size_t up_n = 0;     // upscaled Y (band)
+    float* c2 = nullptr;    size_t c2_n = 0;     // 32 layer-2 planes (band)
+    float* planes = nullptr; size_t planes_n = 0; // colour shell: split planes / Y' / resized chroma planes
+    unsigned char* bytes = nullptr; size_t bytes_n = 0;
+    bool frozen = false;    // a captured graph has these pointers baked in: growing is an error
+    size_t footprint() const { return sizeof(float) * (tmp_n + up_n + c2_n + planes_n) + bytes_n; }
+    void release()
+    {
+        (void)hipFree(tmp); (void)hipFree(up); (void)hipFree(c2); (void)hipFree(planes); (void)hipFree(bytes);
+        tmp = up = c2 = planes = nullptr; bytes = nullptr;
+        tmp_n = up_n = c2_n = planes_n = bytes_n = 0;
+    }
+};
+
+struct Ctx;
+
+// One invocation of the path: on which context and stream it runs, on which scratch, with which numerics.  The mode is
+// read ONCE at the public entry point, so a concurrent srcnn_set_mode never changes a call half way through, and
+// `timing` is how a graph capture tells the stage timers to stay out (event pairs cannot be timed inside a capture).
+// `hold` keeps every contribution table the call launches with referenced: for an eager call until the call returns
+// (the cache itself only frees after a device sync), for a graph until the graph is destroyed.
+struct Call {
+    Ctx* cx = nullptr;
+    hipStream_t s = nullptr;
+    Workspace* ws = nullptr;
+    int mode = SRCNN_MODE_STRICT;
+    bool timing = true;
+    std::vector<TableRef>* hold = nullptr;
+    bool strict() const { return mode == SRCNN_MODE_STRICT; }
+};
+
+struct StageSpan { hipEvent_t a, b; int stage; };
+
+struct StreamSlot {         // one lane of the host-stream path; lives until srcnn_shutdown
+    hipStream_t st = nullptr;          // kernels (slot 0's stream carries the kernels of BOTH slots)
+    hipStream_t cst = nullptr;         // this slot's copies, in both directions
+    hipEvent_t e_in = nullptr, e_k = nullptr, e_out = nullptr;   // frame landed / kernels done / result copied out
+    float* din = nullptr;  size_t din_n = 0;
+    float* dout = nullptr; size_t dout_n = 0;
+    Workspace ws;                      // private: the captured graph has its pointers baked in
+    std::vector<TableRef> tables;      // references taken by eager runs (trimmed by the runs themselves)
+    std::vector<TableRef> graph_tables; // references baked into `exec`: live exactly as long as the graph
+    hipGraphExec_t exec = nullptr;     // captured kernel sequence for (gw, gh, gmode)
+    unsigned gw = 0, gh = 0; int gmode = -1;
+    unsigned uses = 0;                 // eager runs at the current shape (capture needs one first)
+};
+
+// One lane of srcnn_process_u8 (the ProcessSRCNN surface).  The reference's ProcessSRCNN allocates everything per
+// call and is therefore re-entrant (src/libsrcnn.cpp:628-923); here a call leases a lane -- its own compute and
+// copy streams, scratch, page-locked staging and events -- on every context it uses, for its whole duration, so
+// concurrent calls from several host threads never share a buffer.  Lanes are created on demand up to kMaxLanes per
+// context; further callers wait for one.
+struct ProcLane {
+    bool busy = false;
+    hipStream_t st = nullptr, copy_st = nullptr;
+    Workspace ws;
+    unsigned char* pin_in = nullptr;  size_t pin_in_n = 0;
+    unsigned char* pin_out = nullptr; size_t pin_out_n = 0;
+    std::vector<hipEvent_t> band_events;
+    void release_buffers();
+    void release();
+};
+constexpr size_t kMaxLanes = 4;
+constexpr size_t kMaxTables = 64;      // cache bound per context; only unreferenced tables are ever evicted
+
+// Per-context buffers of the node-level tiled frame (srcnn_y_upscale2x_f32_node_dev): the slab of the source frame this
+// context's band reads, and the band it produces before it is copied to the root device.
+struct NodeLane {
+    hipStream_t st = nullptr, copy_st = nullptr;
+    Workspace ws;
+    float* in = nullptr;   size_t in_n = 0;
+    float* band = nullptr; size_t band_n = 0;
+    std::vector<hipEvent_t> events;
+    void release();
+};
+
+struct Ctx {
+    int index = 0;          // position in Global::ctxs
+    int device = 0;         // physical HIP device
+    int numa_node = -1;     // host NUMA node next to the device (-1: unknown)
+    std::mutex mu;          // tables, ws map, spans, event pool
+    std::vector<StageSpan> spans;          // recorded, not yet read
+    std::vector<hipEvent_t> event_pool;    // recycled events
+    double stage_ms[SRCNN_STAGE_COUNT] = {0, 0, 0};
+    unsigned long long stage_n[SRCNN_STAGE_COUNT] = {0, 0, 0};
+    int num_cus = 256;
+    FusedF16Weights* fused_w = nullptr;   // device copy of the fused fp16 kernel's weight image
+    std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
+    unsigned long long table_clock = 0;
+    std::map<hipStream_t, std::unique_ptr<Workspace>> ws;
+    StreamSlot slots[2];
+    std::mutex stream_mu;               // the host-stream path is serialised per context
+    std::mutex lane_mu;                 // ProcessSRCNN lanes
+    std::condition_variable lane_cv;
+    std::vector<std::unique_ptr<ProcLane>> lanes;
+    std::mutex node_mu;                 // the node-level tiled frame is serialised per context
+    NodeLane node;
+};
+
+struct Global {
+    std::mutex mu;                                   // guards ctxs (creation / shutdown) and stream_ctx
+    std::vector<std::unique_ptr<Ctx>> ctxs;
+    std::atomic<int> nctx{0};                        // == ctxs.size(), readable without the lock
+    std::map<hipStream_t, int> stream_ctx;           // streams made by srcnn_stream_create -> owning context
+    std::atomic<bool> profiling{false};
+    std::atomic<int> mode{SRCNN_MODE_STRICT};
+    std::atomic<size_t> ws_budget;
+    int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
+    bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
+    bool resample_two_pass = false;   // SRCNN_RESAMPLE_2PASS=1: always the two separate resampler passes (A/B testing)
+    bool resample_old2d = false;      // SRCNN_RESAMPLE_OLD2D=1: the round-2 one-launch kernel instead of k_rs2d (A/B testing)
+    bool shell_unfused = false;       // SRCNN_SHELL_UNFUSED=1: colour shell as split + plane resamples + merge (A/B testing)
+    bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
+    bool numa = true;           // SRCNN_NUMA=0: do not place page-locked staging on the device's NUMA node
+    Global();
+};
+extern Global& G;
+
+// ---- contexts ----
+int ensure_init();                       // at least context 0 exists (lazy: device 0, or env SRCNN_DEVICES)
+Ctx* cur_ctx();                          // the calling thread's current context, device bound; nullptr + error if init fails
+Ctx* ctx_for_stream(void* stream);       // the context that owns `stream` (srcnn_stream_create), else the current one
+int bind(Ctx& cx);                       // hipSetDevice(cx.device) for the calling thread
+int context_count();
+Ctx* context_at(int k);
+
+// ---- scratch / tables ----
+template <class T>
+int grow(T*& p, size_t& have, size_t want)
+{
+    if (want <= have) return SRCNN_OK;
+    if (p) {
+        // kernels launched earlier (any stream) may still be using the old block: drain before freeing it
+        (void)hipDeviceSynchronize();
+        (void)hipFree(p);
+        p = nullptr; have = 0;
+    }
+    void* q = nullptr;
+    if (hipMalloc(&q, want * sizeof(T)) != hipSuccess)
+        return fail(SRCNN_E_DEVMEM, "hipMalloc(%zu bytes) failed", want * sizeof(T));
+    p = static_cast<T*>(q);
+    have = want;
+    return SRCNN_OK;
+}
+
+template <class T>
+int grow_ws(Workspace& ws, T*& p, size_t& have, size_t want)
+{
+    if (want <= have) return SRCNN_OK;
+    if (ws.frozen) return fail(SRCNN_E_ARG, "workspace of a captured graph cannot grow (%zu > %zu elements)", want, have);
+    return grow(p, have, want);
+}
+
+int get_table(Call& c, int filter, unsigned dst_len, unsigned src_len, TableRef& out);
+Workspace* workspace_for(Ctx& cx, hipStream_t s);
+void* pinned_alloc(Ctx& cx, size_t bytes);      // page-locked, visible to every device, on the context's NUMA node
+int grow_pinned(Ctx& cx, unsigned char*& p, size_t& have, size_t want);
+
+// ---- the path (srcnn_capi.cpp) ----
+int check_plane(const void* in, unsigned w, unsigned h, const void* out);
+int check_y_path_args(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, const float* d_out);
+int resample_rows_range(Call& c, const float* d_in, unsigned sw, unsigned sh, unsigned dw, unsigned dh, int filter,
+                        unsigned r0, unsigned r1, float* d_dst);
+int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+                unsigned r0, unsigned r1, float* d_out);
+int y_path_range(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
+                 unsigned r0, unsigned r1, float* d_out);
+int y_path_frame(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* d_out);
+// source rows [lo, hi) of a (w x h) plane that output rows [r0, r1) of the Y path (resample + 3 layers) depend on
+int y_path_source_rows(Call& c, unsigned h, unsigned dh, int filter, unsigned r0, unsigned r1, unsigned& lo, unsigned& hi);
+// rows of layer-2 scratch one band may hold under the workspace budget (>= 16), for a dw-wide output
+unsigned budget_band_rows(unsigned dw);
+
+// memcpy split over a few host threads: the destination is usually a fresh new[] block whose pages fault in on first
+// touch, which a single thread does at only a few GB/s.
+void parallel_memcpy(void* dst, const void* src, size_t n);
+
+// An ordered hand-off between a producer and ONE consumer thread (replaces the round-2 yield() spin loops): the producer
+// publishes "items [0, n) are ready", the consumer blocks in wait_for(i) until item i is ready or the hand-off is
+// cancelled.  Nobody spins.
+class Handoff {
+public:
+    void publish(unsigned n) { { std::lock_guard<std::mutex> lk(m_); ready_ = n; } cv_.notify_all(); }
+    void cancel() { { std::lock_guard<std::mutex> lk(m_); cancelled_ = true; } cv_.notify_all(); }
+    bool wait_for(unsigned i)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return ready_ > i || cancelled_; });
+        return ready_ > i;
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    unsigned ready_ = 0;
+    bool cancelled_ = false;
+};
+
+// Lease of one ProcessSRCNN lane of a context for the duration of a call.
+struct LaneLease {
+    Ctx* cx = nullptr;
+    ProcLane* lane = nullptr;
+    int rc = SRCNN_OK;
+    explicit LaneLease(Ctx& cx);
+    ~LaneLease();
+    LaneLease(const LaneLease&) = delete;
+    LaneLease& operator=(const LaneLease&) = delete;
+};
+
+}  // namespace srcnn

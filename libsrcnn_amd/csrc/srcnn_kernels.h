@@ -28,6 +28,20 @@ struct DevAxisTable {          // device pointers into one uploaded AxisTable
     const double* weight;
     int stride;
     int max_taps;
+    int monotone;              // first[] and first[]+taps[] are non-decreasing (checked on the host when the table is built)
+    const int* h_first;        // HOST copies of first[] / taps[] (launch planning: tile spans), or NULL
+    const int* h_taps;
+};
+
+// Where the Y resampler reads its source samples: a planar float32 plane, or an interleaved 8-bit RGB(A) image whose
+// Y = 0.299 R + 0.587 G + 0.114 B is computed per sample exactly as converImgU8toYCbCr does (src/libsrcnn.cpp:233-272),
+// so that the colour split never has to materialise a Y plane.
+struct YSource {
+    const float* plane = nullptr;
+    const unsigned char* rgb = nullptr;
+    int depth = 0;
+    static YSource from_plane(const float* p) { YSource y; y.plane = p; return y; }
+    static YSource from_rgb(const unsigned char* p, int d) { YSource y; y.rgb = p; y.depth = d; return y; }
 };
 
 // Weight image of the fused fp16 kernel (srcnn_fused_f16.hip): every fp32 weight, pre-scaled by 2^8, split into
@@ -68,7 +82,20 @@ void launch_resample_cols(const float* src, int w, int src_row_base, float* dst,
                           const DevAxisTable& t, hipStream_t s);
 void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, int rows, const DevAxisTable& t,
                           hipStream_t s);
-// both passes of an up-scale in one kernel; returns false (nothing launched) when the shape does not qualify
+// Round-3 resampler (k_rs2d): both passes of an up-scale in one kernel, 4 output columns per thread with 16-byte
+// stores, tile spans in closed form from the (monotone) tables.  `src` may be an RGB(A) image (Y computed on the fly).
+// Returns false (nothing launched) when the shape does not qualify; the caller then falls back to the older kernels.
+bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
+                 const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s);
+// Colour merge with the chroma (and alpha) planes resampled on the fly from the SOURCE image (src/libsrcnn.cpp:665-726
+// per-plane resample + :274-308 merge, fused): for output rows [dst_row0, +dst_rows) reads the interleaved source
+// image and the finished Y' rows (Yp: row dst_row0 at offset 0), writes interleaved u8 (rgb_out: row dst_row0 at offset 0)
+// and optionally the truncated Y' (conv_opt).  The destination-size Cb / Cr / A planes never exist.  Same per-sample
+// arithmetic and order as the separate kernels.  Returns false when the shape does not qualify.
+bool launch_merge_fused(const unsigned char* rgb_src, int src_w, int src_h, int depth, const float* Yp,
+                        unsigned char* rgb_out, unsigned char* conv_opt, int dst_w, int dst_h, int dst_row0, int dst_rows,
+                        const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s);
+// both passes of an up-scale in one kernel (round 2); returns false (nothing launched) when the shape does not qualify
 bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
                         const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s);
 void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,

@@ -23,6 +23,7 @@
 // them into LDS per block in operand (lane) order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "srcnn_kernels.h"
 
@@ -193,6 +194,235 @@ __global__ __launch_bounds__(R2_TW) void k_resample_2d(
         for (int t = 0; t < RS_MAXT; ++t)
             if (t < n) acc = acc + w[t] * (double)in[t];
         dst[(size_t)(ry0 + r) * dst_w + x] = (float)acc;
+    }
+}
+
+// =============================================================================================
+// Round-3 resampler family k_rs2d: both passes of an up-scale in ONE kernel (vertical first, then horizontal, as
+// src/frawscale.cpp:238-278 orders them), same operations in the same order as k_resample_cols + k_resample_rows.
+//   * a block owns a 256-column x TH-row output tile; a lane owns FOUR adjacent output columns (16-byte stores, one wave
+//     = one 1 KB row segment) and keeps their horizontal weights in registers for all its rows;
+//   * the tile's source span is known in closed form: the tables are monotone (checked on the host when they are built),
+//     so first[] of the tile's first row/column and first[]+taps[] of its last give the patch -- a handful of scalar
+//     loads, no reduction, and the patch loads are issued at once, in one batch of independent loads;
+//   * the vertical pass is spread over ALL threads of the block (item = (row, source column)), not over columns only
+//     (at 2x only half of the threads had a column);
+//   * the source can be an interleaved 8-bit RGB(A) image (KIND 1: Y computed per sample exactly like k_rgb_split), and
+//     the sink can be the colour merge (KIND 2: the block resamples Cb, Cr (and A) from the source image and merges them
+//     with the finished Y' rows straight into interleaved u8 -- src/libsrcnn.cpp:274-308 -- so the destination-size chroma
+//     planes never exist).
+// LDS (dynamic): vertical weights, then per plane the source patch [sr][lw] and the intermediate rows [TH][lw] (fp32,
+// i.e. rounded after the vertical pass like the reference's intermediate image).  sr / lw are the largest spans any
+// tile of THIS launch has, computed on the host from the table's host copy.
+// =============================================================================================
+struct Rs2dArgs {
+    const float* src_plane; const unsigned char* src_rgb; int src_w;
+    float* dst;                               // KIND 0/1: rows [dst_row0, +dst_rows), row dst_row0 at offset 0
+    const float* yp; unsigned char* out_rgb; unsigned char* out_conv;   // KIND 2 (same row convention)
+    int dst_w, dst_row0, dst_rows;
+    int lw, sr;                               // LDS row stride (floats) and patch rows
+    const int* vfirst; const int* vtaps; const double* vwt; int vstride;
+    const int* hfirst; const int* htaps; const double* hwt; int hstride;
+    int vec;                                  // 16-byte / dword accesses are aligned for this launch
+};
+
+__device__ __forceinline__ unsigned char to_u8_sat(float v)
+{   // MIN(255.f, v) then MAX(0.f, .) then truncating cast, in the reference's macro forms
+    v = (255.f < v) ? 255.f : v;
+    v = (0.f > v) ? 0.f : v;
+    return (unsigned char)v;
+}
+
+template <int KIND, int D>
+__device__ __forceinline__ void rs_load(const Rs2dArgs& a, int r, int c, float* v)
+{
+    if constexpr (KIND == 0) {
+        v[0] = a.src_plane[(size_t)r * a.src_w + c];
+    } else {
+        const unsigned char* q = a.src_rgb + ((size_t)r * a.src_w + c) * D;
+        const float R = (float)q[0], Gc = (float)q[1], B = (float)q[2];
+        if constexpr (KIND == 1) {
+            v[0] = (0.299f * R) + (0.587f * Gc) + (0.114f * B);                  // src/libsrcnn.cpp:251-256
+        } else {
+            v[0] = 128.f - (0.1687f * R) - (0.3313f * Gc) + (0.5f * B);
+            v[1] = 128.f + (0.5f * R) - (0.4187f * Gc) - (0.0813f * B);
+            if constexpr (D == 4) v[2] = (float)q[3];
+        }
+    }
+}
+
+template <int KIND, int D, int MAXT, int TH, bool CONV>
+__global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
+{
+    constexpr int NP = (KIND == 2) ? D - 1 : 1;
+    constexpr int U = 4;                       // patch items per thread per batch of independent loads
+    constexpr int RPT = TH / 4;                // rows per thread in the horizontal pass
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
+    double* vw = reinterpret_cast<double*>(rs_lds);            // [TH][MAXT]
+    int* vf = reinterpret_cast<int*>(vw + TH * MAXT);          // [TH] first source row, relative to the patch
+    int* vn = vf + TH;                                         // [TH] taps
+    float* raw = reinterpret_cast<float*>(vn + TH);            // [NP][sr][lw]
+    float* mid = raw + (size_t)NP * a.sr * a.lw;               // [NP][TH][lw]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0t = blockIdx.x * 256;
+    const int xl = min(x0t + 256, a.dst_w) - 1;
+    const int ry0 = blockIdx.y * TH;
+    const int rows = min(TH, a.dst_rows - ry0);
+    const int y0 = a.dst_row0 + ry0, yl = y0 + rows - 1;
+    // closed-form spans (monotone tables): wave-uniform scalar loads
+    const int c0 = a.hfirst[x0t], cn = a.hfirst[xl] + a.htaps[xl] - c0;
+    const int vmin = a.vfirst[y0], nsrc = a.vfirst[yl] + a.vtaps[yl] - vmin;
+
+    // ---- everything that comes from global memory is requested now ----
+    // (1) KIND 2: the Y' values this thread will merge with
+    float yv[RPT][4];
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = wv + 4 * k;
+            const int x = x0t + 4 * lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yv[k][j] = 0.f;
+            if (r < rows && x < a.dst_w) {
+                const float* yr = a.yp + (size_t)(ry0 + r) * a.dst_w + x;
+                if (a.vec) { const float4 q = *reinterpret_cast<const float4*>(yr); yv[k][0] = q.x; yv[k][1] = q.y; yv[k][2] = q.z; yv[k][3] = q.w; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (x + j < a.dst_w) yv[k][j] = yr[j];
+                }
+            }
+        }
+    }
+    // (2) the horizontal weights of this thread's four columns
+    int s0[4], n[4];
+    double w[4][MAXT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xc = min(x0t + 4 * lane + j, a.dst_w - 1);
+        s0[j] = a.hfirst[xc] - c0; n[j] = a.htaps[xc];
+        const double* wr = a.hwt + (size_t)xc * a.hstride;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) w[j][t] = t < n[j] ? wr[t] : 0.0;
+    }
+    // (3) the vertical weights of the tile's rows
+    if (tid < TH * MAXT) {
+        const int r = tid / MAXT, t = tid - r * MAXT;
+        if (r < rows) {
+            const int y = y0 + r;
+            const int cnt = a.vtaps[y];
+            vw[tid] = t < cnt ? a.vwt[(size_t)y * a.vstride + t] : 0.0;
+            if (t == 0) { vf[r] = a.vfirst[y] - vmin; vn[r] = cnt; }
+        }
+    }
+    // (4) the source patch: rows [vmin, vmin+nsrc) x columns [c0, c0+cn), item i = r*cn + c, U independent loads at a time
+    {
+        const int total = nsrc * cn;
+        const int qstep = 256 / cn, rstep = 256 - qstep * cn;      // (r, c) advance of 256 items
+        int r = tid / cn, c = tid - r * cn;
+        for (int base = 0; base < total; base += 256 * U) {
+            float v[U][NP];
+            int ro[U], co[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ro[u] = r; co[u] = c;
+                if (base + tid + 256 * u < total) rs_load<KIND, D>(a, vmin + r, c0 + c, v[u]);
+                c += rstep; r += qstep;
+                if (c >= cn) { c -= cn; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (base + tid + 256 * u < total) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) raw[((size_t)p * a.sr + ro[u]) * a.lw + co[u]] = v[u][p];
+                }
+        }
+    }
+    __syncthreads();
+    // ---- vertical pass over (row, source column) items: same products, same order as k_resample_cols ----
+    {
+        const int total = rows * cn;
+        const int qstep = 256 / cn, rstep = 256 - qstep * cn;
+        int r = tid / cn, c = tid - r * cn;
+        for (int i = tid; i < total; i += 256) {
+            const int rb = vf[r], cnt = vn[r];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float* col = raw + ((size_t)p * a.sr + rb) * a.lw + c;
+                double acc = 0.0;
+                for (int t = 0; t < cnt; ++t) acc = acc + vw[r * MAXT + t] * (double)col[(size_t)t * a.lw];
+                mid[((size_t)p * TH + r) * a.lw + c] = (float)acc;
+            }
+            c += rstep; r += qstep;
+            if (c >= cn) { c -= cn; ++r; }
+        }
+    }
+    __syncthreads();
+    // ---- horizontal pass (same as k_resample_rows_reg), four columns per lane, then the sink ----
+    const int x = x0t + 4 * lane;
+    if (x >= a.dst_w) return;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = wv + 4 * k;
+        if (r >= rows) break;
+        float o[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float* in = mid + ((size_t)p * TH + r) * a.lw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+                    if (t < n[j]) acc = acc + w[j][t] * (double)in[s0[j] + t];
+                o[p][j] = (float)acc;
+            }
+        }
+        const size_t pix = (size_t)(ry0 + r) * a.dst_w + x;
+        if constexpr (KIND != 2) {
+            float* dr = a.dst + pix;
+            if (a.vec) *reinterpret_cast<float4*>(dr) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (x + j < a.dst_w) dr[j] = o[0][j];
+            }
+        } else {
+            unsigned char px[4][4];
+            unsigned cw = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float fy = yv[k][j], cb = o[0][j] - 128.f, cr = o[1][j] - 128.f;     // src/libsrcnn.cpp:289-299
+                px[j][0] = to_u8_sat(fy + 45.f * cr / 32.f);
+                px[j][1] = to_u8_sat(fy - (11.f * cb + 23.f * cr) / 32.f);
+                px[j][2] = to_u8_sat(fy + 113.f * cb / 64.f);
+                px[j][3] = 0;
+                if constexpr (D == 4) px[j][3] = to_u8_sat(o[NP - 1][j]);
+                cw |= (unsigned)(unsigned char)fy << (8 * j);                              // src/libsrcnn.cpp:897-901
+            }
+            unsigned char* orow = a.out_rgb + pix * D;
+            if (a.vec) {
+                unsigned wds[D] = {};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ch = 0; ch < D; ++ch) {
+                        const int byte = j * D + ch;
+                        wds[byte >> 2] |= (unsigned)px[j][ch] << (8 * (byte & 3));
+                    }
+                unsigned* o32 = reinterpret_cast<unsigned*>(orow);
+#pragma unroll
+                for (int q = 0; q < D; ++q) o32[q] = wds[q];
+                if constexpr (CONV) *reinterpret_cast<unsigned*>(a.out_conv + pix) = cw;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x + j < a.dst_w) {
+#pragma unroll
+                        for (int ch = 0; ch < D; ++ch) orow[j * D + ch] = px[j][ch];
+                        if constexpr (CONV) a.out_conv[pix + j] = (unsigned char)(cw >> (8 * j));
+                    }
+            }
+        }
     }
 }
 
@@ -982,13 +1212,6 @@ __global__ __launch_bounds__(256) void k_rgb_split(const unsigned char* __restri
     if (d == 4) A[p] = (float)rgb[p * d + 3];
 }
 
-__device__ __forceinline__ unsigned char to_u8_sat(float v)
-{   // MIN(255.f, v) then MAX(0.f, .) then truncating cast, in the reference's macro forms
-    v = (255.f < v) ? 255.f : v;
-    v = (0.f > v) ? 0.f : v;
-    return (unsigned char)v;
-}
-
 __global__ __launch_bounds__(256) void k_ycc_merge(const float* __restrict__ Yp, const float* __restrict__ Cb,
                                                    const float* __restrict__ Cr, const float* __restrict__ A,
                                                    size_t n, int d, unsigned char* __restrict__ rgb,
@@ -1043,6 +1266,88 @@ bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int 
     if (grid.y > 65535u) return false;
     hipLaunchKernelGGL(k_resample_2d, grid, dim3(R2_TW), 0, s, src, src_w, dst, dst_w, dst_row0, dst_rows, tv.first, tv.taps,
                        tv.weight, tv.stride, th.first, th.taps, th.weight, th.stride);
+    return true;
+}
+
+// ---- k_rs2d launchers ----
+static inline bool aligned_to(const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+namespace {
+struct Rs2dPlan { int lw = 0, sr = 0, maxt = 0, th = 16; size_t lds = 0; unsigned gx = 0, gy = 0; bool ok = false; };
+
+// Tile spans of one launch from the tables' host copies (the tables are monotone, so a tile's span is given by its ends).
+Rs2dPlan rs2d_plan(int np, int dst_w, int dst_row0, int dst_rows, const DevAxisTable& tv, const DevAxisTable& th)
+{
+    Rs2dPlan p;
+    if (dst_rows <= 0 || dst_w <= 0 || !tv.monotone || !th.monotone || !tv.h_first || !th.h_first) return p;
+    const int m = std::max(tv.max_taps, th.max_taps);
+    if (m > 8) return p;
+    p.maxt = m <= 4 ? 4 : (m <= 6 ? 6 : 8);
+    static const int th_env = [] { const char* e = getenv("SRCNN_RS_TH"); return e ? atoi(e) : 0; }();
+    p.th = (th_env == 32) ? 32 : 16;
+    for (int x0 = 0; x0 < dst_w; x0 += 256) {
+        const int xl = std::min(x0 + 256, dst_w) - 1;
+        p.lw = std::max(p.lw, th.h_first[xl] + th.h_taps[xl] - th.h_first[x0]);
+    }
+    for (int r = 0; r < dst_rows; r += p.th) {
+        const int y0 = dst_row0 + r, yl = dst_row0 + std::min(r + p.th, dst_rows) - 1;
+        p.sr = std::max(p.sr, tv.h_first[yl] + tv.h_taps[yl] - tv.h_first[y0]);
+    }
+    p.lw = (p.lw + 1) & ~1;
+    p.lds = (size_t)p.th * p.maxt * sizeof(double) + (size_t)p.th * 2 * sizeof(int) + (size_t)np * (p.sr + p.th) * p.lw * sizeof(float);
+    p.gx = cdiv(dst_w, 256); p.gy = cdiv(dst_rows, p.th);
+    p.ok = p.lds <= 64 * 1024 && p.gy <= 65535u && p.lw > 0 && p.sr > 0;
+    return p;
+}
+
+template <int KIND, int D, bool CONV>
+void rs2d_dispatch(const Rs2dPlan& p, const Rs2dArgs& a, hipStream_t s)
+{
+    const dim3 grid(p.gx, p.gy), block(256);
+#define RS_GO(MT, TH_) hipLaunchKernelGGL((k_rs2d<KIND, D, MT, TH_, CONV>), grid, block, p.lds, s, a)
+    if (p.th == 32) { if (p.maxt == 4) RS_GO(4, 32); else if (p.maxt == 6) RS_GO(6, 32); else RS_GO(8, 32); }
+    else            { if (p.maxt == 4) RS_GO(4, 16); else if (p.maxt == 6) RS_GO(6, 16); else RS_GO(8, 16); }
+#undef RS_GO
+}
+}  // namespace
+
+bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
+                 const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s)
+{
+    if (dst_w < src_w || dst_h < src_h) return false;
+    if (!src.plane && !(src.rgb && (src.depth == 3 || src.depth == 4))) return false;
+    const Rs2dPlan p = rs2d_plan(1, dst_w, dst_row0, dst_rows, tv, th);
+    if (!p.ok) return false;
+    Rs2dArgs a{};
+    a.src_plane = src.plane; a.src_rgb = src.rgb; a.src_w = src_w;
+    a.dst = dst; a.dst_w = dst_w; a.dst_row0 = dst_row0; a.dst_rows = dst_rows;
+    a.lw = p.lw; a.sr = p.sr;
+    a.vfirst = tv.first; a.vtaps = tv.taps; a.vwt = tv.weight; a.vstride = tv.stride;
+    a.hfirst = th.first; a.htaps = th.taps; a.hwt = th.weight; a.hstride = th.stride;
+    a.vec = (dst_w % 4 == 0) && aligned_to(dst, 16);
+    if (src.plane) rs2d_dispatch<0, 3, false>(p, a, s);
+    else if (src.depth == 3) rs2d_dispatch<1, 3, false>(p, a, s);
+    else rs2d_dispatch<1, 4, false>(p, a, s);
+    return true;
+}
+
+bool launch_merge_fused(const unsigned char* rgb_src, int src_w, int src_h, int depth, const float* Yp,
+                        unsigned char* rgb_out, unsigned char* conv_opt, int dst_w, int dst_h, int dst_row0, int dst_rows,
+                        const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s)
+{
+    if (dst_w < src_w || dst_h < src_h || (depth != 3 && depth != 4)) return false;
+    const Rs2dPlan p = rs2d_plan(depth - 1, dst_w, dst_row0, dst_rows, tv, th);
+    if (!p.ok) return false;
+    Rs2dArgs a{};
+    a.src_rgb = rgb_src; a.src_w = src_w;
+    a.yp = Yp; a.out_rgb = rgb_out; a.out_conv = conv_opt;
+    a.dst_w = dst_w; a.dst_row0 = dst_row0; a.dst_rows = dst_rows;
+    a.lw = p.lw; a.sr = p.sr;
+    a.vfirst = tv.first; a.vtaps = tv.taps; a.vwt = tv.weight; a.vstride = tv.stride;
+    a.hfirst = th.first; a.htaps = th.taps; a.hwt = th.weight; a.hstride = th.stride;
+    a.vec = (dst_w % 4 == 0) && aligned_to(Yp, 16) && aligned_to(rgb_out, 4) && (!conv_opt || aligned_to(conv_opt, 4));
+    if (depth == 3) { if (conv_opt) rs2d_dispatch<2, 3, true>(p, a, s); else rs2d_dispatch<2, 3, false>(p, a, s); }
+    else            { if (conv_opt) rs2d_dispatch<2, 4, true>(p, a, s); else rs2d_dispatch<2, 4, false>(p, a, s); }
     return true;
 }
 

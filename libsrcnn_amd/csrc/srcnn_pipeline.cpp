@@ -1,0 +1,611 @@
+// srcnn_pipeline.cpp -- the host-pointer side of the C ABI: frames and images that live in HOST memory go through
+// copy / compute / copy pipelines here, on one context or dealt over all contexts of the process (node level).
+//
+//   srcnn_y_upscale2x_f32_stream   stream of planar-float Y frames (BASELINE config #5): two device slots per context,
+//                                  one hipGraph per slot; with several contexts the frames are dealt to them in
+//                                  contiguous chunks, one worker thread per context.
+//   srcnn_process_u8               the ProcessSRCNN surface (src/libsrcnn.cpp:628-923 = one doSRCNN pass): the output is
+//                                  produced in horizontal bands; per band: stage the source rows the band needs (host
+//                                  memcpy -> page-locked staging -> H2D), kernels, D2H into page-locked staging, fan-out to
+//                                  the caller's buffer.  With several contexts the bands are dealt to the node's devices.
+//   srcnn_y_upscale2x_f32_node_dev ONE device-resident frame tiled over all contexts of this process: each context pulls
+//                                  the source rows its band needs from the root device (hipMemcpyPeerAsync), computes the
+//                                  band in sub-bands, and pushes every finished sub-band to the root while the next one
+//                                  computes (the single-process counterpart of the RCCL band gather).
+//
+// Every copy/kernel dependency that involves a copy engine is resolved on the HOST by a helper thread that BLOCKS
+// (hipEventSynchronize / condition variable): on this runtime a copy that waits device-side on another queue's event does
+// not overlap that queue's kernels (profiles/r02_stream_overlap.txt), and the round-2 yield() spin loops are gone.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include "srcnn_host.hpp"
+
+namespace srcnn {
+namespace {
+
+bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    const bool yes = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return yes;
+}
+
+// Start a helper thread; false (and nothing started) if the system refuses -- callers then run the work inline.
+template <class F>
+bool try_thread(std::thread& t, F&& f)
+{
+    try { t = std::thread(std::forward<F>(f)); return true; }
+    catch (...) { return false; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Frame stream on ONE context.  in/out are already page-locked (or pageable: the copies then just do not overlap).
+// ------------------------------------------------------------------------------------------------------------------
+int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph, int mode)
+{
+    int rc = bind(cx);
+    if (rc) return rc;
+    const size_t in_n = (size_t)w * h, out_n = in_n * 4;
+    const size_t in_b = in_n * sizeof(float), out_b = out_n * sizeof(float);
+    std::lock_guard<std::mutex> slk(cx.stream_mu);
+    const int nslots = nframes > 1 ? 2 : 1;
+    for (int i = 0; i < nslots && !rc; ++i) {
+        StreamSlot& sl = cx.slots[i];
+        if (!sl.st && hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
+        if (!rc && !sl.cst && hipStreamCreateWithFlags(&sl.cst, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
+        for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out})
+            if (!rc && !*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = fail(SRCNN_E_HIP, "event create");
+        if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) {     // shape or mode changed: drop the graph first,
+            if (sl.exec) { (void)hipStreamSynchronize(cx.slots[0].st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
+            sl.ws.frozen = false;                                          // then its buffers may move again
+            sl.graph_tables.clear();
+            sl.tables.clear();
+            sl.gw = w; sl.gh = h; sl.gmode = mode; sl.uses = 0;
+        }
+        if (!rc) rc = grow(sl.din, sl.din_n, in_n);
+        if (!rc) rc = grow(sl.dout, sl.dout_n, out_n);
+    }
+    if (rc) return rc;
+    // Pipeline.  Copies run on the slots' copy-only streams and every copy/kernel dependency that involves a copy is
+    // resolved on the HOST (see the file header; measured with tools/hs_probe.py, 4K frames: 12.2-12.4 ms per frame with
+    // the D2H on the kernel stream or behind hipStreamWaitEvent, 10.8 ms when the host waits for the kernels and then
+    // queues the copy on an idle stream).  A copier thread waits for frame f's kernels and then issues its D2H; the main
+    // thread waits for the slot's previous D2H before it reuses the slot.  Both block; neither spins.
+    Handoff launched;      // frames whose kernels have been queued (e_k recorded)
+    Handoff copied;        // frames whose D2H has been queued (e_out recorded)
+    std::atomic<int> copy_err{0};
+    auto copy_frame = [&](unsigned f) {
+        StreamSlot& sl = cx.slots[f % nslots];
+        if (hipEventSynchronize(sl.e_k) != hipSuccess ||
+            hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.cst) != hipSuccess ||
+            hipEventRecord(sl.e_out, sl.cst) != hipSuccess) copy_err = 1;
+        copied.publish(f + 1);
+    };
+    std::thread copier;
+    const bool threaded = try_thread(copier, [&] {
+        (void)hipSetDevice(cx.device);
+        for (unsigned f = 0; f < nframes; ++f) {
+            if (!launched.wait_for(f)) return;
+            copy_frame(f);
+        }
+    });
+    hipStream_t ks = cx.slots[0].st;       // ALL kernels go to one stream: frames back to back, never two frames' kernels
+                                           // sharing the chip (that costs more than it overlaps: the persistent layer-1+2
+                                           // kernel partitions its tiles over the workgroups it expects to be resident)
+    for (unsigned f = 0; f < nframes && !rc; ++f) {
+        StreamSlot& sl = cx.slots[f % nslots];
+        Call c;
+        c.cx = &cx; c.s = ks; c.ws = &sl.ws; c.mode = mode; c.hold = &sl.tables;
+        if (f >= (unsigned)nslots) {
+            // the slot's previous frame: its kernels are done (the copier saw e_k) once its D2H has been queued; wait for
+            // that D2H to finish before din / dout are reused
+            if (threaded && !copied.wait_for(f - nslots)) { rc = fail(SRCNN_E_HIP, "frame stream cancelled"); break; }
+            if (hipEventSynchronize(sl.e_out) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
+        }
+        // frame in: also resolved on the host (the previous frame's kernels keep the device busy meanwhile)
+        if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.cst) != hipSuccess ||
+            hipEventRecord(sl.e_in, sl.cst) != hipSuccess || hipEventSynchronize(sl.e_in) != hipSuccess) {
+            rc = fail(SRCNN_E_HIP, "H2D"); break;
+        }
+        if (use_graph && sl.uses >= 1 && !sl.exec) {
+            // The slot has run this shape eagerly once: tables and workspaces exist, so the kernel sequence
+            // can be captured without any allocation inside the capture.  The graph's table references are kept apart
+            // from the eager runs' (which trim theirs), for exactly as long as the graph lives.
+            hipGraph_t graph = nullptr;
+            sl.ws.frozen = true;
+            c.timing = false;              // event pairs cannot be timed inside a capture
+            c.hold = &sl.graph_tables;
+            if (hipStreamBeginCapture(ks, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
+            if (!rc) rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
+            if (hipStreamEndCapture(ks, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
+            c.timing = true;
+            c.hold = &sl.tables;
+            if (!rc && hipGraphInstantiate(&sl.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(SRCNN_E_HIP, "graph instantiate");
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) { sl.ws.frozen = false; sl.graph_tables.clear(); break; }
+        }
+        if (use_graph && sl.exec) {
+            if (hipGraphLaunch(sl.exec, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
+        } else {
+            if (sl.exec && sl.ws.frozen) {
+                // an eager call on a slot that still holds a graph of this shape: the graph (and the frozen workspace
+                // and table references it needs) stays valid, the eager run uses the same buffers
+            }
+            if (sl.tables.size() > 16) sl.tables.clear();   // eager runs re-take their references every frame
+            rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
+            if (rc) break;
+        }
+        if (hipEventRecord(sl.e_k, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "event record"); break; }
+        ++sl.uses;
+        if (threaded) launched.publish(f + 1);
+        else copy_frame(f);
+    }
+    if (rc) launched.cancel();             // the copier stops at the first frame that was never launched
+    if (threaded) copier.join();
+    for (int i = 0; i < nslots; ++i) {
+        if (cx.slots[i].st) (void)hipStreamSynchronize(cx.slots[i].st);
+        if (cx.slots[i].cst) (void)hipStreamSynchronize(cx.slots[i].cst);
+    }
+    if (!rc && copy_err) rc = fail(SRCNN_E_HIP, "a device-to-host copy of the frame stream failed");
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ProcessSRCNN surface.
+// ------------------------------------------------------------------------------------------------------------------
+struct ProcJob {            // one srcnn_process_u8 call; shared (read-only) by its per-context workers
+    const unsigned char* rgb; unsigned w, h, d, dw, dh; int filter, cfilter, mode;
+    unsigned char* out; unsigned char* conv;
+    bool trace;
+};
+
+// Bands of a share [R0,R1): few and large at the front (every launch of the persistent layer kernels pays a ramp), small
+// at the end (the last band's D2H + fan-out cannot overlap anything).  Also no band larger than the workspace budget allows.
+std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, bool first_share_of_many)
+{
+    const unsigned rows = R1 - R0;
+    const unsigned cap = budget_band_rows(dw);
+    std::vector<unsigned> cuts{R0};
+    if (rows >= 512) {
+        // 40 % / 30 % / 18 % / 12 % (a share of a multi-context call: 50 / 30 / 20)
+        static const double four[] = {0.40, 0.70, 0.88}, three[] = {0.50, 0.80};
+        const double* f = first_share_of_many ? three : four;
+        const int nf = first_share_of_many ? 2 : 3;
+        for (int i = 0; i < nf; ++i) cuts.push_back(R0 + ((unsigned)(rows * f[i]) & ~15u));
+    }
+    cuts.push_back(R1);
+    // enforce the budget: split anything larger than `cap` rows
+    std::vector<unsigned> out{R0};
+    for (size_t i = 1; i < cuts.size(); ++i) {
+        unsigned a = out.back();
+        const unsigned b = cuts[i];
+        if (b <= a) continue;
+        while (b - a > cap) { a += cap; out.push_back(a); }
+        out.push_back(b);
+    }
+    return out;
+}
+
+// One context's share of a ProcessSRCNN call: output rows [R0,R1), pipelined over bands.
+int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_of_many)
+{
+    int rc = bind(cx);
+    if (rc) return rc;
+    LaneLease lease(cx);
+    if (lease.rc) return lease.rc;
+    ProcLane& L = *lease.lane;
+    Workspace& ws = L.ws;
+    hipStream_t s = L.st;
+    std::vector<TableRef> tables;
+    Call c;
+    c.cx = &cx; c.s = s; c.ws = &ws; c.mode = J.mode; c.hold = &tables;
+    const unsigned w = J.w, h = J.h, d = J.d, dw = J.dw, dh = J.dh;
+    const size_t n = (size_t)w * h;
+    const auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+
+    // A lane that once served a much larger image gives its memory back before it grows for this one
+    {
+        const size_t need = n * d + (size_t)(R1 - R0) * dw * (d + 1 + 4 + 8) + (size_t)C2N * dw * std::min<size_t>(R1 - R0, budget_band_rows(dw)) * 4;
+        const size_t have = ws.footprint() + L.pin_in_n + L.pin_out_n;
+        if (have > (256u << 20) && have > 8 * need) { (void)hipStreamSynchronize(L.st); (void)hipStreamSynchronize(L.copy_st); L.release_buffers(); }
+    }
+
+    // ---- which source rows does this share read?  (the Y path's vertical taps + halo, and the chroma taps) ----
+    unsigned lo = 0, hi = h;
+    TableRef cv, ch_, yv, yh;
+    const bool identity = (dw == w && dh == h);
+    if (!identity) {
+        if ((rc = y_path_source_rows(c, h, dh, J.filter, R0, R1, lo, hi))) return rc;
+        if (dh != h) {
+            if ((rc = get_table(c, J.cfilter, dh, h, cv))) return rc;
+            unsigned clo, chi;
+            cv->source_span(R0, R1, clo, chi);
+            lo = std::min(lo, clo); hi = std::max(hi, std::min(chi, h));
+        } else { lo = std::min(lo, R0); hi = std::max(hi, R1); }
+    }
+    // The fused shell reads the interleaved source directly (no split, no destination-size chroma planes); it needs an
+    // up-scale in both axes with short monotone tables -- anything else takes the plane path below.
+    bool fused_shell = !G.shell_unfused && !identity && dw > w && dh > h;
+    if (fused_shell) {
+        if ((rc = get_table(c, J.cfilter, dw, w, ch_))) return rc;
+        if ((rc = get_table(c, J.filter, dh, h, yv))) return rc;
+        if ((rc = get_table(c, J.filter, dw, w, yh))) return rc;
+        for (const TableRef& t : {cv, ch_, yv, yh}) if (!t->monotone || t->max_taps > 8) fused_shell = false;
+    }
+
+    // ---- device buffers (the lane's grow-only scratch) ----
+    const size_t share_px = (size_t)(R1 - R0) * dw;
+    //   bytes:  [source image (whole-frame geometry; only rows lo..hi are ever written/read)] [out bands] [conv bands]
+    if ((rc = grow_ws(ws, ws.bytes, ws.bytes_n, n * d + share_px * d + share_px))) return rc;
+    unsigned char* d_rgb = ws.bytes;
+    unsigned char* d_out = ws.bytes + n * d;                 // row R0 at offset 0
+    unsigned char* d_conv = d_out + share_px * d;
+    //   planes: [Y' of the share] and, on the plane path only, [Y Cb Cr A at source size] [Cb' Cr' A' of the share]
+    const size_t planes_need = share_px + (fused_shell ? 0 : 4 * n + 3 * share_px);
+    if ((rc = grow_ws(ws, ws.planes, ws.planes_n, planes_need))) return rc;
+    float* yp = ws.planes;                                    // Y', row R0 at offset 0
+    float* sp[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* dp[4] = {yp, nullptr, nullptr, nullptr};
+    if (!fused_shell) {
+        for (int k = 0; k < 4; ++k) sp[k] = ws.planes + share_px + k * n;
+        for (int k = 1; k < 4; ++k) dp[k] = ws.planes + share_px + 4 * n + (k - 1) * share_px;
+    }
+
+    // ---- bands ----
+    const std::vector<unsigned> cuts = band_starts(R0, R1, dw, one_of_many);
+    const unsigned nb = (unsigned)cuts.size() - 1;
+    unsigned max_band = 0;
+    for (unsigned b = 0; b < nb; ++b) max_band = std::max(max_band, cuts[b + 1] - cuts[b]);
+    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !G.f16_unfused;           // the fused kernel has no layer-2 planes
+    if (!no_planes && (rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
+    if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * std::min(dh, max_band + 12)))) return rc;
+    if (!fused_shell && (rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
+    while (L.band_events.size() < 2 * nb + 1) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        L.band_events.push_back(e);
+    }
+
+    const size_t out_bytes = share_px * d;
+    const bool small = out_bytes < (8u << 20) && !one_of_many;
+    // ---- stage-in: the share's source rows.  Small images go straight from the caller's (pageable) buffer. ----
+    const size_t src_off = (size_t)lo * w * d, src_bytes = (size_t)(hi - lo) * w * d;
+    if (small) {
+        HIP_TRY(hipMemcpyAsync(d_rgb + src_off, J.rgb + src_off, src_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        if ((rc = grow_pinned(cx, L.pin_in, L.pin_in_n, src_bytes))) return rc;
+        if ((rc = grow_pinned(cx, L.pin_out, L.pin_out_n, out_bytes + share_px))) return rc;
+        parallel_memcpy(L.pin_in, J.rgb + src_off, src_bytes);
+        HIP_TRY(hipMemcpyAsync(d_rgb + src_off, L.pin_in, src_bytes, hipMemcpyHostToDevice, s));
+    }
+    if (!fused_shell)
+        launch_rgb_split(d_rgb + src_off, (size_t)(hi - lo) * w, (int)d, sp[0] + (size_t)lo * w, sp[1] + (size_t)lo * w,
+                         sp[2] + (size_t)lo * w, sp[3] + (size_t)lo * w, s);
+    const auto t1 = now();
+
+    const YSource ysrc = fused_shell ? YSource::from_rgb(d_rgb, (int)d) : YSource::from_plane(sp[0]);
+    auto run_band = [&](unsigned a, unsigned b) -> int {       // kernels of output rows [a,b)
+        const size_t p0 = (size_t)(a - R0) * dw, pn = (size_t)(b - a) * dw;
+        int r = y_path_rows(c, ysrc, w, h, dw, dh, J.filter, a, b, yp + p0);
+        if (r) return r;
+        if (fused_shell) {
+            const DevAxisTable tv = cv->view(), th = ch_->view();
+            if (!launch_merge_fused(d_rgb, (int)w, (int)h, (int)d, yp + p0, d_out + p0 * d, J.conv ? d_conv + p0 : nullptr,
+                                    (int)dw, (int)dh, (int)a, (int)(b - a), tv, th, s))
+                return fail(SRCNN_E_UNSUPPORTED, "fused colour shell refused a shape it was selected for");
+        } else {
+            for (unsigned k = 1; k < d; ++k)
+                if ((r = resample_rows_range(c, sp[k], w, h, dw, dh, J.cfilter, a, b, dp[k] + p0))) return r;
+            launch_ycc_merge(yp + p0, dp[1] + p0, dp[2] + p0, dp[3] ? dp[3] + p0 : nullptr, pn, (int)d, d_out + p0 * d,
+                             J.conv ? d_conv + p0 : nullptr, s);
+        }
+        HIP_TRY(hipGetLastError());
+        return SRCNN_OK;
+    };
+
+    if (small) {
+        // small image: one shot on the lane's stream
+        if ((rc = run_band(R0, R1))) return rc;
+        HIP_TRY(hipMemcpyAsync(J.out + (size_t)R0 * dw * d, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        if (J.conv) HIP_TRY(hipMemcpyAsync(J.conv + (size_t)R0 * dw, d_conv, share_px, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return SRCNN_OK;
+    }
+
+    // Large image: the reference's only benchmark is the wall time of this call (src/test.cpp:653-672), and for a GPU
+    // that is dominated by moving ~4 B per output pixel to and from pageable host memory.  So: page-locked staging on both
+    // sides, the output produced in bands (bit-identical to the whole frame, tests/test_gpu_parity.py::
+    // test_bands_equal_whole_frame), each band's D2H on the copy stream while the next band computes, and a helper thread
+    // that fans each landed band out to the caller's buffers.  The helper blocks on events; it never spins.
+    unsigned char* pin_rgb = L.pin_out;
+    unsigned char* pin_conv = L.pin_out + out_bytes;
+    std::atomic<int> copy_err{0};
+    Handoff enqueued;                       // bands whose kernels have been queued (their "computed" event recorded)
+    auto d2h_band = [&](unsigned b) {
+        const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
+        if (hipEventSynchronize(L.band_events[2 * b]) != hipSuccess ||
+            hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
+            (J.conv && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess) ||
+            hipEventRecord(L.band_events[2 * b + 1], L.copy_st) != hipSuccess) { copy_err = 1; return false; }
+        return true;
+    };
+    auto fan_band = [&](unsigned b) {
+        if (hipEventSynchronize(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
+        const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
+        const size_t g0 = (size_t)cuts[b] * dw;
+        parallel_memcpy(J.out + g0 * d, pin_rgb + p0 * d, pn * d);
+        if (J.conv) parallel_memcpy(J.conv + g0, pin_conv + p0, pn);
+    };
+    std::thread fanout;
+    const bool threaded = try_thread(fanout, [&] {
+        (void)hipSetDevice(cx.device);
+        // resolve the copy dependencies on the host: wait for a band's kernels, queue its D2H on the idle copy stream, and
+        // fan the previous band out to the caller's buffers while that copy is in flight
+        unsigned done = 0;
+        bool any = false;
+        for (unsigned b = 0; b < nb; ++b) {
+            if (!enqueued.wait_for(b)) break;
+            if (!d2h_band(b)) return;
+            if (b > 0) fan_band(b - 1);
+            done = b; any = true;
+        }
+        if (any) fan_band(done);
+    });
+    int launch_rc = SRCNN_OK;
+    for (unsigned b = 0; b < nb; ++b) {
+        launch_rc = run_band(cuts[b], cuts[b + 1]);
+        if (!launch_rc && hipEventRecord(L.band_events[2 * b], s) != hipSuccess) launch_rc = fail(SRCNN_E_HIP, "band %u event record failed", b);
+        if (launch_rc) { enqueued.cancel(); break; }
+        if (threaded) enqueued.publish(b + 1);
+        else if (d2h_band(b)) fan_band(b);
+    }
+    if (threaded) fanout.join();
+    const auto t2 = now();
+    hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(L.copy_st);
+    if (launch_rc) return launch_rc;
+    if (e1 != hipSuccess || e2 != hipSuccess || copy_err) return fail(SRCNN_E_HIP, "pipeline failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    HIP_TRY(hipGetLastError());
+    if (J.trace) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        fprintf(stderr, "srcnn_process_u8 ctx %d (device %d) rows [%u,%u) of %ux%ux%u x%.2f: stage-in %.2f ms, %u bands (compute || D2H || fan-out) %.2f ms%s\n",
+                cx.index, cx.device, R0, R1, w, h, d, (double)dw / w, ms(t0, t1), nb, ms(t1, t2), fused_shell ? ", fused shell" : "");
+    }
+    return SRCNN_OK;
+}
+
+}  // namespace
+}  // namespace srcnn
+
+using namespace srcnn;
+
+extern "C" {
+
+// ---- host-pointer conveniences -----------------------------------------------------------------
+int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* out)
+{
+    int rc;
+    if ((rc = check_plane(in, w, h, out))) return rc;
+    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    if (!cur_ctx()) return SRCNN_E_NODEVICE;
+    float *d_in = nullptr, *d_out = nullptr;
+    const size_t in_b = sizeof(float) * (size_t)w * h, out_b = sizeof(float) * (size_t)dw * dh;
+    if (hipMalloc((void**)&d_in, in_b) != hipSuccess || hipMalloc((void**)&d_out, out_b) != hipSuccess) {
+        hipFree(d_in);
+        return fail(SRCNN_E_DEVMEM, "device allocation of %zu+%zu bytes failed", in_b, out_b);
+    }
+    rc = SRCNN_OK;
+    if (hipMemcpy(d_in, in, in_b, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SRCNN_E_HIP, "H2D copy failed");
+    if (!rc) rc = srcnn_y_path_f32_dev(d_in, w, h, dw, dh, filter, d_out, nullptr);
+    if (!rc && hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SRCNN_E_HIP, "D2H copy failed");
+    hipFree(d_in); hipFree(d_out);
+    return rc;
+}
+
+int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out)
+{
+    return srcnn_y_path_f32(in, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, out);
+}
+
+int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph)
+{
+    int rc;
+    if ((rc = check_plane(in, w, h, out))) return rc;
+    if (nframes == 0) return fail(SRCNN_E_ARG, "nframes == 0");
+    Ctx* cur = cur_ctx();
+    if (!cur) return SRCNN_E_NODEVICE;
+    const size_t in_n = (size_t)w * h, out_n = in_n * 4;
+    const size_t in_b = in_n * sizeof(float), out_b = out_n * sizeof(float);
+    const int mode = G.mode.load();
+
+    // page-lock the caller's frames so the copies are truly asynchronous -- unless they already are (buffers from
+    // srcnn_host_alloc_pinned / hipHostMalloc: registering a gigabyte again costs milliseconds per call); harmless if it fails
+    const bool reg_in = !is_pinned(in) && hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterPortable) == hipSuccess;
+    const bool reg_out = !is_pinned(out) && hipHostRegister(out, out_b * nframes, hipHostRegisterPortable) == hipSuccess;
+    (void)hipGetLastError();
+
+    // Frames are independent: with several contexts they are dealt out in contiguous chunks, one worker per context
+    // (no data-path exchange at all; each context runs its own two-slot pipeline).
+    const unsigned nctx = (unsigned)std::min<unsigned>((unsigned)context_count(), nframes);
+    if (nctx <= 1) {
+        rc = stream_on_ctx(*cur, in, w, h, nframes, out, use_graph, mode);
+    } else {
+        std::vector<int> rcs(nctx, SRCNN_OK);
+        std::vector<std::string> errs(nctx);
+        std::vector<std::thread> th(nctx);
+        auto work = [&](unsigned k) {
+            const unsigned f0 = (unsigned)((unsigned long long)nframes * k / nctx), f1 = (unsigned)((unsigned long long)nframes * (k + 1) / nctx);
+            Ctx* cx = context_at((int)k);
+            rcs[k] = cx ? stream_on_ctx(*cx, in + f0 * in_n, w, h, f1 - f0, out + f0 * out_n, use_graph, mode) : SRCNN_E_NODEVICE;
+            if (rcs[k]) errs[k] = srcnn_last_error();
+        };
+        std::vector<bool> started(nctx, false);
+        for (unsigned k = 1; k < nctx; ++k) started[k] = try_thread(th[k], [&, k] { work(k); });
+        work(0);
+        for (unsigned k = 1; k < nctx; ++k) { if (started[k]) th[k].join(); else work(k); }
+        for (unsigned k = 0; k < nctx; ++k)
+            if (rcs[k]) { rc = rcs[k]; set_last_error(errs[k].c_str()); break; }
+        (void)bind(*cur);
+    }
+    if (reg_in) (void)hipHostUnregister(const_cast<float*>(in));
+    if (reg_out) (void)hipHostUnregister(out);
+    return rc;
+}
+
+int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigned nframes, float* out)
+{
+    return srcnn_y_upscale2x_f32_stream(in, w, h, nframes, out, 0);
+}
+
+int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
+                     unsigned char* out, unsigned char* conv_opt)
+{
+    if (!rgb || !out || w == 0 || h == 0 || d == 0) return fail(SRCNN_E_ARG, "NULL pointer or zero dimension");
+    if (d != 3 && d != 4) return fail(SRCNN_E_UNSUPPORTED, "depth %u: the reference reads uninitialised planes for d<3 (src/libsrcnn.cpp:235-236)", d);
+    if ((float)w * multiply <= 0.f || (float)h * multiply <= 0.f) return fail(SRCNN_E_SCALE, "non-positive scaled size");
+    if (filter < 0 || filter > 4) return fail(SRCNN_E_ARG, "bad filter %d", filter);
+    Ctx* cur = cur_ctx();
+    if (!cur) return SRCNN_E_NODEVICE;
+    const unsigned dw = (unsigned)((float)w * multiply), dh = (unsigned)((float)h * multiply);   // src/libsrcnn.cpp:662-663
+    if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
+    if ((unsigned long long)w * h > 0x7fffffffULL || (unsigned long long)dw * dh > 0x7fffffffULL)
+        return fail(SRCNN_E_UNSUPPORTED, "plane too large");
+    ProcJob J;
+    J.rgb = rgb; J.w = w; J.h = h; J.d = d; J.dw = dw; J.dh = dh; J.filter = filter;
+    J.cfilter = (filter == SRCNN_FILTER_NEAREST) ? SRCNN_FILTER_NEAREST : SRCNN_FILTER_BILINEAR;   // src/libsrcnn.cpp:701-713
+    J.mode = G.mode.load(); J.out = out; J.conv = conv_opt;
+    J.trace = getenv("SRCNN_TRACE") != nullptr;
+
+    // Everything runs on lanes leased for this call only (see ProcLane): concurrent ProcessSRCNN calls from several host
+    // threads are independent, like the reference's.  A large image is dealt over all contexts of the process in
+    // contiguous row shares proportional to nothing but their count (the devices of a node are identical): the
+    // reference's one call saturates its whole machine (src/libsrcnn.cpp:665,791-798,817-824), and so does this one.
+    const size_t out_bytes = (size_t)dw * dh * d;
+    unsigned shares = 1;
+    if (out_bytes >= (8u << 20)) shares = std::max(1u, std::min<unsigned>((unsigned)context_count(), dh / 256u));
+    if (shares <= 1) return process_share(*cur, J, 0, dh, false);
+
+    std::vector<int> rcs(shares, SRCNN_OK);
+    std::vector<std::string> errs(shares);
+    std::vector<std::thread> th(shares);
+    // the calling thread's context takes share 0, the others follow in context order
+    auto ctx_of_share = [&](unsigned k) { return context_at((int)((cur->index + k) % (unsigned)context_count())); };
+    auto work = [&](unsigned k) {
+        const unsigned r0 = (unsigned)((unsigned long long)dh * k / shares) & ~15u;
+        const unsigned r1 = (k + 1 == shares) ? dh : ((unsigned)((unsigned long long)dh * (k + 1) / shares) & ~15u);
+        Ctx* cx = ctx_of_share(k);
+        rcs[k] = cx ? process_share(*cx, J, r0, r1, true) : SRCNN_E_NODEVICE;
+        if (rcs[k]) errs[k] = srcnn_last_error();
+    };
+    std::vector<bool> started(shares, false);
+    for (unsigned k = 1; k < shares; ++k) started[k] = try_thread(th[k], [&, k] { work(k); });
+    work(0);
+    for (unsigned k = 1; k < shares; ++k) { if (started[k]) th[k].join(); else work(k); }
+    (void)bind(*cur);
+    for (unsigned k = 0; k < shares; ++k)
+        if (rcs[k]) { set_last_error(errs[k].c_str()); return rcs[k]; }
+    return SRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ONE device-resident frame tiled over all contexts of this process (BASELINE config #4 from a single process).
+// d_in / d_out live on the calling thread's current context (the root).
+// ------------------------------------------------------------------------------------------------------------------
+int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, float* d_out, int sub_bands)
+{
+    int rc;
+    if ((rc = check_plane(d_in, w, h, d_out))) return rc;
+    Ctx* root = cur_ctx();
+    if (!root) return SRCNN_E_NODEVICE;
+    const unsigned dw = 2 * w, dh = 2 * h;
+    if (dh > (1u << 20) || dw > 0x7fffffu) return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large", dw, dh);
+    const unsigned nctx = std::max(1u, std::min<unsigned>((unsigned)context_count(), dh / 64u));
+    const unsigned nsub = (unsigned)std::max(1, std::min(sub_bands <= 0 ? 4 : sub_bands, 16));
+    const int mode = G.mode.load();
+    // the caller's earlier work on the root's default stream (uploads, a previous frame) must be visible to the workers
+    HIP_TRY(hipDeviceSynchronize());
+
+    std::vector<int> rcs(nctx, SRCNN_OK);
+    std::vector<std::string> errs(nctx);
+    auto work = [&](unsigned k) -> int {
+        Ctx& cx = *context_at((int)((root->index + k) % (unsigned)context_count()));
+        int r = bind(cx);
+        if (r) return r;
+        std::lock_guard<std::mutex> nlk(cx.node_mu);
+        NodeLane& N = cx.node;
+        if (!N.st) HIP_TRY(hipStreamCreateWithFlags(&N.st, hipStreamNonBlocking));
+        if (!N.copy_st) HIP_TRY(hipStreamCreateWithFlags(&N.copy_st, hipStreamNonBlocking));
+        const unsigned R0 = (unsigned)((unsigned long long)dh * k / nctx), R1 = (unsigned)((unsigned long long)dh * (k + 1) / nctx);
+        if (R1 <= R0) return SRCNN_OK;
+        std::vector<TableRef> tables;
+        Call c;
+        c.cx = &cx; c.s = N.st; c.ws = &N.ws; c.mode = mode; c.hold = &tables;
+        const bool is_root = (&cx == root);
+        // source rows of this band, pulled from the root device into a buffer with whole-frame geometry
+        unsigned lo = 0, hi = h;
+        if ((r = y_path_source_rows(c, h, dh, SRCNN_FILTER_BICUBIC, R0, R1, lo, hi))) return r;
+        const float* src = d_in;
+        if (!is_root) {
+            if ((r = grow(N.in, N.in_n, (size_t)w * h))) return r;
+            if ((r = grow(N.band, N.band_n, (size_t)(R1 - R0) * dw))) return r;
+            HIP_TRY(hipMemcpyPeerAsync(N.in + (size_t)lo * w, cx.device, d_in + (size_t)lo * w, root->device,
+                                       sizeof(float) * (size_t)(hi - lo) * w, N.st));
+            src = N.in;
+        }
+        while (N.events.size() < nsub) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            N.events.push_back(e);
+        }
+        // sub-bands: the kernels of sub-band i+1 are queued before the host waits for sub-band i and pushes it to the root
+        // on the copy stream, so the push (one xGMI link per peer, all peers concurrently) hides behind compute
+        std::vector<unsigned> cut(nsub + 1);
+        for (unsigned i = 0; i <= nsub; ++i) cut[i] = R0 + (unsigned)((unsigned long long)(R1 - R0) * i / nsub);
+        auto launch = [&](unsigned i) -> int {
+            if (cut[i + 1] <= cut[i]) return SRCNN_OK;
+            float* dst = is_root ? d_out + (size_t)cut[i] * dw : N.band + (size_t)(cut[i] - R0) * dw;
+            int q = y_path_range(c, src, w, h, dw, dh, SRCNN_FILTER_BICUBIC, cut[i], cut[i + 1], dst);
+            if (q) return q;
+            HIP_TRY(hipEventRecord(N.events[i], N.st));
+            return SRCNN_OK;
+        };
+        auto push = [&](unsigned i) -> int {
+            if (is_root || cut[i + 1] <= cut[i]) return SRCNN_OK;
+            HIP_TRY(hipEventSynchronize(N.events[i]));
+            HIP_TRY(hipMemcpyPeerAsync(d_out + (size_t)cut[i] * dw, root->device, N.band + (size_t)(cut[i] - R0) * dw, cx.device,
+                                       sizeof(float) * (size_t)(cut[i + 1] - cut[i]) * dw, N.copy_st));
+            return SRCNN_OK;
+        };
+        if ((r = launch(0))) return r;
+        for (unsigned i = 0; i < nsub; ++i) {
+            if (i + 1 < nsub && (r = launch(i + 1))) return r;
+            if ((r = push(i))) return r;
+        }
+        HIP_TRY(hipStreamSynchronize(N.st));
+        HIP_TRY(hipStreamSynchronize(N.copy_st));
+        return SRCNN_OK;
+    };
+    std::vector<std::thread> th(nctx);
+    std::vector<bool> started(nctx, false);
+    auto run = [&](unsigned k) { rcs[k] = work(k); if (rcs[k]) errs[k] = srcnn_last_error(); };
+    for (unsigned k = 1; k < nctx; ++k) started[k] = try_thread(th[k], [&, k] { run(k); });
+    run(0);
+    for (unsigned k = 1; k < nctx; ++k) { if (started[k]) th[k].join(); else run(k); }
+    (void)bind(*root);
+    for (unsigned k = 0; k < nctx; ++k)
+        if (rcs[k]) { set_last_error(errs[k].c_str()); return rcs[k]; }
+    return SRCNN_OK;
+}
+
+}  // extern "C"

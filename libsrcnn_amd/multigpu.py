@@ -118,26 +118,29 @@ def gpu_compute_band(d_in, w, h, row0, rows, d_band, stream=None):
 
 
 class TiledFrameGPU:
-    """The device side of upscale2x_frame_tiled: this rank's band through srcnn_y_upscale2x_f32_band_dev, then ONE
-    collective -- srcnn_comm_gatherv_f32, peer->root, per-rank counts -- into a contiguous (2h x 2w) frame on the
-    root.  Buffers are allocated once; step() is what bench.py times."""
+    """The device side of upscale2x_frame_tiled, one process per GPU: srcnn_comm_tiled_y_upscale2x_f32_dev computes this
+    rank's band in `nsub` pieces and gathers piece k (RCCL peer->root ncclSend/ncclRecv, explicit offsets, ragged bands
+    allowed) on the library's comm stream while piece k+1 computes, into a contiguous (2h x 2w) frame on the root.
+    Buffers are allocated once; step() is what bench.py times (the caller synchronises)."""
 
-    def __init__(self, w, h, rank, world, root=0):
+    def __init__(self, w, h, rank, world, root=0, nsub=4):
         import ctypes as C
         import libsrcnn_amd as S
         self.S, self.w, self.h, self.rank, self.world, self.root = S, w, h, rank, world, root
-        self.row0, self.rows = band_rows(2 * h, rank, world)
-        self.counts = (C.c_size_t * world)(*[band_rows(2 * h, r, world)[1] * 2 * w for r in range(world)])
+        self.nsub = max(1, int(nsub))
+        r0, rows = C.c_uint(0), C.c_uint(0)
+        S.check(S.lib().srcnn_band_rows(2 * h, rank, world, C.byref(r0), C.byref(rows)))
+        self.row0, self.rows = r0.value, rows.value
+        assert (self.row0, self.rows) == band_rows(2 * h, rank, world)      # the C partition is the one the CPU tests cover
         self.d_band = S.DeviceBuffer(max(1, self.rows) * 2 * w * 4)
         self.d_full = S.DeviceBuffer(4 * w * h * 4) if rank == root else None
 
     def step(self, d_in, stream=None):
         S, L = self.S, self.S.lib()
-        if self.rows:
-            S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, self.w, self.h, self.row0, self.rows, self.d_band.ptr, stream))
-        S.check(L.srcnn_comm_gatherv_f32(self.d_band.ptr, self.counts, self.d_full.ptr if self.d_full else None,
-                                         self.root, stream))
+        S.check(L.srcnn_comm_tiled_y_upscale2x_f32_dev(d_in.ptr, self.w, self.h, self.d_band.ptr,
+                                                       self.d_full.ptr if self.d_full else None, self.root, self.nsub, stream))
 
     def result(self):
         """Host copy of the assembled frame (root only)."""
+        self.S.sync()
         return self.d_full.to_numpy(np.float32, (2 * self.h, 2 * self.w))

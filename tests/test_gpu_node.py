@@ -1,0 +1,74 @@
+"""Node-level paths (one process, several contexts) on the one GPU the test box has: K VIRTUAL contexts that alias device 0.
+Each test runs tests/node_worker.py in a process of its own (contexts are process-wide).  The bar is the same as
+everywhere: the oracle's bytes / the whole-frame call's bits."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "node_worker.py")
+
+
+def run(cmd, arg=0, env=None, timeout=900):
+    e = dict(os.environ)
+    e.pop("SRCNN_DEVICES", None)
+    if env:
+        e.update(env)
+    r = subprocess.run([sys.executable, WORKER, cmd, str(arg)], env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_processsrcnn_over_4_virtual_contexts():
+    """The reference's one ProcessSRCNN call uses its whole machine (src/libsrcnn.cpp:665,791-798,817-824); with 4 contexts
+    ours deals the bands of a large image to all of them: byte-equal to the oracle, to the one-context result at 4K, and
+    under 4 concurrent host threads."""
+    r = run("process", 4)
+    assert r["contexts"] == 4
+    assert all(r["vs_oracle"]), r
+    assert r["lanes_after_oracle_cases"] >= 4                    # every context took part
+    assert not r["thread_errors"], r
+    assert r["big_rc"] == 0 and r["big_equal"] and r["big_rows_vs_oracle"], r
+    assert r["contexts_after_reinit"] == 1
+
+
+@pytest.mark.parametrize("nctx", [3, 8])
+def test_node_tiled_frame_equals_whole_frame(nctx):
+    r = run("node_tiled", nctx)
+    assert r["contexts"] == nctx
+    assert all(c["equal"] for c in r["cases"]), r
+    assert r["vs_oracle"]
+
+
+def test_host_stream_dealt_over_contexts():
+    r = run("stream", 2)
+    assert r["contexts"] == 2 and all(r["equal"]) and r["single_frame"], r
+
+
+def test_rccl_tiled_call_with_overlapped_sub_band_gather():
+    r = run("comm_tiled")
+    assert all(c["equal"] for c in r["cases"]), r
+    assert r["gatherv_at"]
+
+
+def test_env_srcnn_devices_self_init():
+    r = run("env_devices", env={"SRCNN_DEVICES": "0,0,0"})
+    assert r["contexts"] == 3 and r["equal"] and r["process_equal"] and r["lanes"] >= 3, r
+    r = run("env_devices", env={"SRCNN_DEVICES": "all"})
+    assert r["contexts"] == 1 and r["equal"] and r["process_equal"], r
+
+
+@pytest.mark.parametrize("env", [{}, {"SRCNN_SHELL_UNFUSED": "1"}, {"SRCNN_RESAMPLE_OLD2D": "1", "SRCNN_SHELL_UNFUSED": "1"},
+                                 {"SRCNN_RESAMPLE_2PASS": "1", "SRCNN_SHELL_UNFUSED": "1"}, {"SRCNN_RS_TH": "32"},
+                                 {"SRCNN_MAX_WORKSPACE_MB": "48"}, {"SRCNN_NUMA": "0"}],
+                         ids=["default", "unfused-shell", "round2-resampler", "two-pass", "th32", "small-budget", "no-numa"])
+def test_processsrcnn_kernel_selections_all_bit_exact(env):
+    """The fused colour shell / k_rs2d (default) and every fallback they replace produce the oracle's bytes; so does a
+    workspace budget small enough to force many bands inside srcnn_process_u8."""
+    r = run("process_paths", env=env)
+    assert all(r["process"]), (env, r)
+    assert all(r["y"]), (env, r)

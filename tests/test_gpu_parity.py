@@ -468,3 +468,70 @@ def test_batch_graph_replay_equals_eager(srcnn):
     S.check(S.lib().srcnn_batch_graph_destroy(h))
     st.destroy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------
+# the ONE deliberate deviation from the reference, pinned from both sides
+# ------------------------------------------------------------------------------------------------
+def test_identity_size_deviation_is_pinned(srcnn, oracle_lib):
+    """FRAWResizeEngine::scale with dst size == src size copies sizeof(unsigned short) = 2 bytes per pixel into a fresh
+    buffer (/root/reference/src/frawscale.cpp:185-193): the first HALF of the float plane is copied, the second half is
+    whatever the allocation held.  The oracle restates that (over a zeroed buffer).  The product copies the WHOLE plane,
+    i.e. treats the identity resample as the identity -- this test states both behaviours next to each other, for the
+    resampler alone, for the float Y path and for ProcessSRCNN(multiply = 1.0)."""
+    S = srcnn
+    h, w = 22, 36
+    y = synth.plane(h, w, synth.SEED0 + 4242, "noise") + 1.0          # no zeros, so "zero" below means "not copied"
+    n = h * w
+    # (1) resampler alone
+    ref = oracle_lib.resample(y, w, h).ravel()
+    assert np.array_equal(ref[: n // 2], y.ravel()[: n // 2]) and not ref[n // 2:].any()      # the reference's half copy
+    got = S.resample(y, w, h)
+    assert_bit_equal(got, y, "product: identity-size resample is the identity")
+    # (2) float Y path at dw == w, dh == h: the three layers applied to the plane itself
+    want = oracle_lib.conv3(oracle_lib.conv2(oracle_lib.conv1(y)))
+    assert_bit_equal(S.y_path(y, w, h), want, "product: y_path at identity size")
+    assert not np.array_equal(oracle_lib.y_path(y, w, h), want)       # ... which is NOT what the half copy gives
+    # mixed: one axis unchanged is an ordinary resample on both sides (only dw == w AND dh == h takes the branch)
+    assert_bit_equal(S.y_path(y, 2 * w, h), oracle_lib.y_path(y, 2 * w, h), "only-x resample")
+    # (3) ProcessSRCNN with multiply 1.0: colour split, identity resample of every plane, the layers on Y, merge -- restated
+    #     here in float32 numpy with the reference's expressions (src/libsrcnn.cpp:251-262, 289-299, 897-901)
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    f = np.float32
+    r, g, b = (img[..., k].astype(np.float32) for k in range(3))
+    yy = (f(0.299) * r) + (f(0.587) * g) + (f(0.114) * b)
+    cb = f(128.0) - (f(0.1687) * r) - (f(0.3313) * g) + (f(0.5) * b)
+    cr = f(128.0) + (f(0.5) * r) - (f(0.4187) * g) - (f(0.0813) * b)
+    y3 = oracle_lib.conv3(oracle_lib.conv2(oracle_lib.conv1(yy)))
+    cbm, crm = cb - f(128.0), cr - f(128.0)
+
+    def sat(v):
+        return np.minimum(f(255.0), np.maximum(f(0.0), v)).astype(np.uint8)
+    want_rgb = np.stack([sat(y3 + f(45.0) * crm / f(32.0)), sat(y3 - (f(11.0) * cbm + f(23.0) * crm) / f(32.0)),
+                         sat(y3 + f(113.0) * cbm / f(64.0))], axis=-1)
+    S.ConfigureFilterSRCNN(S.SRCNNF_Bicubic, False)
+    rc, out, conv = S.ProcessSRCNN(img, w, h, 3, 1.0)
+    assert rc == 0 and out.size == h * w * 3
+    assert np.array_equal(out.reshape(h, w, 3), want_rgb)
+    assert np.array_equal(conv.reshape(h, w), y3.astype(np.uint8))
+    # the reference (oracle) output for the same call differs exactly because of the half copy
+    ref_rgb, _ = oracle_lib.process(img, 1.0)
+    assert ref_rgb.shape == want_rgb.shape and not np.array_equal(ref_rgb, want_rgb)
+
+
+def test_whole_1080p_frame_against_the_compiled_reference(srcnn):
+    """Every one of the 8.3 M output samples of a 1920x1080 -> 3840x2160 frame against the REAL reference
+    (oracle/_ref, compiled from /root/reference/src in the dev container; the C restatement where that did not travel),
+    not just windows.  The frame's seed changes from run to run (printed, so a failure can be replayed with
+    SRCNN_TEST_SEED)."""
+    import os
+    import time
+    import oracle
+    eng = oracle.Reference() if oracle.have_reference() else oracle.Oracle()
+    seed = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(time.time()) & 0xFFFFF)
+    print("whole-frame seed", seed, "engine", type(eng).__name__)
+    y = synth.plane(1080, 1920, synth.SEED0 + seed, "noise" if seed & 1 else "smooth")
+    want = eng.y_path(y)
+    got = srcnn.y_upscale2x(y)
+    assert_bit_equal(got, want, "whole 1080p frame, seed %d" % seed)

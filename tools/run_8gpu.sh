@@ -3,10 +3,13 @@
 #   frames  : resident 4K frames sharded across ranks, no data-path collective   (the headline line, weak scaling)
 #   tiled8k : ONE 7680x4320 frame -> 15360x8640, one output band per rank + RCCL gatherv to rank 0, verified
 #             against the whole-frame result once per run                        (strong scaling)
+#   host-stream : BASELINE config #5 shape -- host-resident 4K frames through the two-slot hipGraph stream path on every
+#             rank, barrier + max over ranks, summed MPix                        (weak scaling, PCIe inclusive)
 # Usage: tools/run_8gpu.sh [--dry-run] [N ...]        default N = 1 2 4 8
 #   --dry-run validates, on the CPU and without touching a device, the rank -> device mapping, per-rank frame
 #   ownership (seed = 0x5C0DE000 + frame index), the band partition and the buffer sizes for every N.
-# The launcher is torch.distributed.run (started BEFORE anything touches the GPU: no exec from a HIP process).
+# bench.py launches its own ranks (subprocess children created before anything touches the GPU: no exec from a HIP
+# process); `python3 -m torch.distributed.run ... bench.py --gpus N` works as well.
 set -euo pipefail
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -33,13 +36,10 @@ print(json.dumps({"world": n,
 PY
         continue
     fi
-    for WL in frames tiled8k; do
+    for WL in frames tiled8k host-stream; do
         echo "== N=$N workload=$WL" >&2
-        if [ "$N" -eq 1 ]; then
-            python3 bench.py --gpus 1 --steps 5 --warmup 2 --workload $WL --no-extras --no-cpu-baseline
-        else
-            python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 \
-                --master-port "$PORT" bench.py --gpus "$N" --steps 5 --warmup 2 --workload $WL
-        fi
+        # bench.py is its own launcher: without WORLD_SIZE in the environment it starts the N ranks itself (fresh children,
+        # the parent never touches the GPU) and prints the one aggregated JSON line
+        python3 bench.py --gpus "$N" --steps 5 --warmup 2 --workload $WL --no-extras --no-cpu-baseline
     done
 done

@@ -3,7 +3,12 @@
 // images are binary Netpbm (P6 RGB, P5 gray -> expanded to RGB as the reference's convImage does at
 // src/test.cpp:56-80, P7 RGB_ALPHA).
 //
-//   srcnntest [--scale=<ratio>] [--step] [--filter=<0..4>] source.ppm [output.ppm]
+//   srcnntest [--scale=<ratio>] [--step] [--filter=<0..4>] [--waitakey] [--devices=all|<id,id,...>] [--repeat=N]
+//             source.ppm [output.ppm]
+//
+// --waitakey pauses before exit like the reference's (src/test.cpp:735-742, there so that a human can watch the process'
+// memory for leaks).  --devices selects the GPUs ONE ProcessSRCNN call may use (default: device 0; "all": every visible
+// device -- the bands of a large image are dealt to them; a list may repeat an id).
 //
 // Writes <source>_resized.ppm (or the given output) and <source>_convolution.pgm (the truncated SRCNN Y
 // plane), and prints the wall time of the ProcessSRCNN call like the reference ("Test Ok, took N ms.").
@@ -92,7 +97,8 @@ std::string stem(const std::string& p)
 int main(int argc, char** argv)
 {
     float scale = 2.0f;                      // the reference's default image_multiply (src/test.cpp:288)
-    bool step = false;
+    bool step = false, waitakey = false;
+    std::string devices;
     int repeat = 1;                          // --repeat=N: call ProcessSRCNN N times, report every wall time
     SRCNNFilterType filt = SRCNNF_Bicubic;
     std::string src, dst;
@@ -100,6 +106,8 @@ int main(int argc, char** argv)
         const std::string a = argv[i];
         if (a.rfind("--scale=", 0) == 0) { const float v = (float)atof(a.c_str() + 8); if (v > 0.f) scale = v; }
         else if (a.rfind("--step", 0) == 0) step = true;
+        else if (a.rfind("--waitakey", 0) == 0) waitakey = true;
+        else if (a.rfind("--devices=", 0) == 0) devices = a.substr(10);
         else if (a.rfind("--repeat=", 0) == 0) repeat = std::max(1, atoi(a.c_str() + 9));
         else if (a.rfind("--filter=", 0) == 0) {
             const int v = atoi(a.c_str() + 9);
@@ -109,7 +117,7 @@ int main(int argc, char** argv)
     }
     if (src.empty()) {
         printf("usage: %s [--scale=<ratio>] [--step] [--filter=<0 nearest|1 bilinear|2 bicubic|3 lanczos3|4 b-spline>] "
-               "source.(ppm|pgm|pam) [output]\n", argv[0]);
+               "[--waitakey] [--devices=all|<id,id,...>] [--repeat=N] source.(ppm|pgm|pam) [output]\n", argv[0]);
         return 0;
     }
     std::vector<unsigned char> img;
@@ -121,9 +129,23 @@ int main(int argc, char** argv)
     const std::string cov = stem(src) + "_convolution.pgm";
 
     char dev[256] = "";
-    if (srcnn_init(0) != 0) { printf("- device init failed: %s\n", srcnn_last_error()); return -200; }
+    int init_rc;
+    if (devices.empty()) init_rc = srcnn_init(0);
+    else if (devices == "all") init_rc = srcnn_init_devices(nullptr, 0);
+    else {
+        std::vector<int> ids;
+        for (const char* p = devices.c_str(); *p;) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            ids.push_back((int)v);
+            p = (*end == ',') ? end + 1 : end;
+        }
+        init_rc = ids.empty() ? -1 : srcnn_init_devices(ids.data(), (int)ids.size());
+    }
+    if (init_rc != 0) { printf("- device init failed: %s\n", srcnn_last_error()); return -200; }
     srcnn_device_name(dev, sizeof dev);
-    printf("- device: %s\n- Image loaded: %ux%ux%u, scaling ratio %.2f, filter %d%s\n", dev, w, h, d, scale, (int)filt,
+    printf("- device: %s, %d context(s)\n- Image loaded: %ux%ux%u, scaling ratio %.2f, filter %d%s\n", dev, srcnn_context_count(), w, h, d, scale, (int)filt,
            step ? ", step scaling" : "");
 
     ConfigureFilterSRCNN(filt, step);
@@ -155,5 +177,10 @@ int main(int argc, char** argv)
     delete[] out;
     delete[] conv;
     srcnn_shutdown();
+    if (waitakey) {                         // src/test.cpp:735-742
+        printf("- Input any key and enter to quit.\n");
+        fflush(stdout);
+        (void)getchar();
+    }
     return ret;
 }
