@@ -182,6 +182,7 @@ int make_context_locked(int device)
     HIP_TRY(hipMalloc((void**)&cx->fused_w, sizeof(FusedF16Weights)));
     HIP_TRY(hipMemcpy(cx->fused_w, fw.get(), sizeof(FusedF16Weights), hipMemcpyHostToDevice));
     HIP_TRY(fused_f16_prepare());
+    HIP_TRY(rs2d_prepare());
     cx->num_cus = prop.multiProcessorCount;
     cx->numa_node = device_numa_node(device);
     // direct copies between the devices of a node (the node-level tiled frame moves its bands with hipMemcpyPeerAsync)

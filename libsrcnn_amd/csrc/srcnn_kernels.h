@@ -87,6 +87,8 @@ void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, in
 // Returns false (nothing launched) when the shape does not qualify; the caller then falls back to the older kernels.
 bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
                  const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s);
+hipError_t rs2d_prepare();      // per device: lets k_rs2d ask for more than 64 KB of dynamic LDS
+bool rs2d_fits(int np, int src_w, int src_h, int dst_w, int dst_h, int r0, int r1, const DevAxisTable& tv, const DevAxisTable& th);
 // Colour merge with the chroma (and alpha) planes resampled on the fly from the SOURCE image (src/libsrcnn.cpp:665-726
 // per-plane resample + :274-308 merge, fused): for output rows [dst_row0, +dst_rows) reads the interleaved source
 // image and the finished Y' rows (Yp: row dst_row0 at offset 0), writes interleaved u8 (rgb_out: row dst_row0 at offset 0)

@@ -200,27 +200,31 @@ __global__ __launch_bounds__(R2_TW) void k_resample_2d(
 // =============================================================================================
 // Round-3 resampler family k_rs2d: both passes of an up-scale in ONE kernel (vertical first, then horizontal, as
 // src/frawscale.cpp:238-278 orders them), same operations in the same order as k_resample_cols + k_resample_rows.
-//   * a block owns a 256-column x TH-row output tile; a lane owns FOUR adjacent output columns (16-byte stores, one wave
-//     = one 1 KB row segment) and keeps their horizontal weights in registers for all its rows;
-//   * the tile's source span is known in closed form: the tables are monotone (checked on the host when they are built),
+//   * a block owns 256 output columns and marches through `tpb` tiles of 16 rows; a lane owns FOUR adjacent output
+//     columns (16-byte stores, one wave = one 1 KB row segment) and keeps their horizontal weights and LDS tap addresses
+//     in registers for the whole march (the weight table, not the image, was the dominant traffic of the round-2 kernel);
+//   * a tile's source span is known in closed form: the tables are monotone (checked on the host when they are built),
 //     so first[] of the tile's first row/column and first[]+taps[] of its last give the patch -- a handful of scalar
-//     loads, no reduction, and the patch loads are issued at once, in one batch of independent loads;
-//   * the vertical pass is spread over ALL threads of the block (item = (row, source column)), not over columns only
-//     (at 2x only half of the threads had a column);
+//     loads, no reduction -- and the patch is fetched in one batch of independent loads;
+//   * no branch inside either tap loop.  Vertical: a wave takes one tile row at a time, so the tap count is wave-uniform
+//     and selects a fully unrolled body (LDS row stride LW is a template parameter: every tap is an immediate offset).
+//     Horizontal: a lane's four columns may have different tap counts; the missing taps get weight 0.0 and read the zero
+//     column every LDS row ends with, which leaves the fp64 accumulator bit-for-bit unchanged (see the kernel);
 //   * the source can be an interleaved 8-bit RGB(A) image (KIND 1: Y computed per sample exactly like k_rgb_split), and
 //     the sink can be the colour merge (KIND 2: the block resamples Cb, Cr (and A) from the source image and merges them
 //     with the finished Y' rows straight into interleaved u8 -- src/libsrcnn.cpp:274-308 -- so the destination-size chroma
 //     planes never exist).
-// LDS (dynamic): vertical weights, then per plane the source patch [sr][lw] and the intermediate rows [TH][lw] (fp32,
-// i.e. rounded after the vertical pass like the reference's intermediate image).  sr / lw are the largest spans any
-// tile of THIS launch has, computed on the host from the table's host copy.
+// LDS (dynamic): vertical weights, then per plane the source patch [sr][LW] and the intermediate rows [16][LW] (fp32,
+// i.e. rounded after the vertical pass like the reference's intermediate image).  sr is the largest row span any tile of
+// THIS launch has, computed on the host from the table's host copy.  Measured (8K plane, 166 MB): 0.075 ms = 2.2 TB/s
+// (round 2: 0.153 ms); the kernel is VALU-bound on its ~60 instructions per output sample, 3 of 5 of them fp64.
 // =============================================================================================
 struct Rs2dArgs {
     const float* src_plane; const unsigned char* src_rgb; int src_w;
     float* dst;                               // KIND 0/1: rows [dst_row0, +dst_rows), row dst_row0 at offset 0
     const float* yp; unsigned char* out_rgb; unsigned char* out_conv;   // KIND 2 (same row convention)
     int dst_w, dst_row0, dst_rows;
-    int lw, sr;                               // LDS row stride (floats) and patch rows
+    int sr, tpb;                              // patch rows in LDS; row tiles a block marches through
     const int* vfirst; const int* vtaps; const double* vwt; int vstride;
     const int* hfirst; const int* htaps; const double* hwt; int hstride;
     int vec;                                  // 16-byte / dword accesses are aligned for this launch
@@ -251,178 +255,221 @@ __device__ __forceinline__ void rs_load(const Rs2dArgs& a, int r, int c, float* 
     }
 }
 
-template <int KIND, int D, int MAXT, int TH, bool CONV>
+constexpr int RS_TH = 16;                      // tile rows
+constexpr int RS_MAX_TPB = 16;                 // row tiles a block may march through (its horizontal weights are loaded once)
+constexpr int rs_lds_bytes(int np, int maxt, int sr, int lw)
+{
+    return RS_TH * maxt * 8 + RS_TH * 2 * 4 + np * (sr + 1 + RS_TH) * lw * 4;
+}
+
+// One tile row of the vertical pass with a compile-time tap count: source rows rb .. rb+CNT-1 of the patch are LW floats
+// apart, so every ds_read after the first address is an immediate offset.  Same products, same order as k_resample_cols.
+template <int CNT, int NP, int MAXT, int LW>
+__device__ __forceinline__ void rs_vertical_row(const float* raw, int raw_plane, float* midrow, const double* vwr, int rb, int cn, int lane)
+{
+    double wg[CNT];
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) wg[t] = vwr[t];
+    for (int c = lane; c < cn; c += 64) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float* col = raw + p * raw_plane + rb * LW + c;
+            float xs[CNT];
+#pragma unroll
+            for (int t = 0; t < CNT; ++t) xs[t] = col[t * LW];
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < CNT; ++t) acc = acc + wg[t] * (double)xs[t];
+            midrow[p * RS_TH * LW + c] = (float)acc;
+        }
+    }
+}
+
+template <int KIND, int D, int MAXT, int LW, bool CONV>
 __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
 {
+    constexpr int TH = RS_TH;
     constexpr int NP = (KIND == 2) ? D - 1 : 1;
     constexpr int U = 4;                       // patch items per thread per batch of independent loads
     constexpr int RPT = TH / 4;                // rows per thread in the horizontal pass
+    constexpr int ZC = LW - 1;                 // the zero column every mid row ends with
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
     double* vw = reinterpret_cast<double*>(rs_lds);            // [TH][MAXT]
     int* vf = reinterpret_cast<int*>(vw + TH * MAXT);          // [TH] first source row, relative to the patch
     int* vn = vf + TH;                                         // [TH] taps
-    float* raw = reinterpret_cast<float*>(vn + TH);            // [NP][sr][lw]
-    float* mid = raw + (size_t)NP * a.sr * a.lw;               // [NP][TH][lw]
+    float* raw = reinterpret_cast<float*>(vn + TH);            // [NP][sr][LW]
+    const int raw_plane = a.sr * LW;
+    float* mid = raw + NP * raw_plane;                         // [NP][TH][LW]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0t = blockIdx.x * 256;
     const int xl = min(x0t + 256, a.dst_w) - 1;
-    const int ry0 = blockIdx.y * TH;
-    const int rows = min(TH, a.dst_rows - ry0);
-    const int y0 = a.dst_row0 + ry0, yl = y0 + rows - 1;
-    // closed-form spans (monotone tables): wave-uniform scalar loads
+    // closed-form column span (monotone tables): wave-uniform scalar loads
     const int c0 = a.hfirst[x0t], cn = a.hfirst[xl] + a.htaps[xl] - c0;
-    const int vmin = a.vfirst[y0], nsrc = a.vfirst[yl] + a.vtaps[yl] - vmin;
 
-    // ---- everything that comes from global memory is requested now ----
-    // (1) KIND 2: the Y' values this thread will merge with
-    float yv[RPT][4];
-    if constexpr (KIND == 2) {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = wv + 4 * k;
-            const int x = x0t + 4 * lane;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) yv[k][j] = 0.f;
-            if (r < rows && x < a.dst_w) {
-                const float* yr = a.yp + (size_t)(ry0 + r) * a.dst_w + x;
-                if (a.vec) { const float4 q = *reinterpret_cast<const float4*>(yr); yv[k][0] = q.x; yv[k][1] = q.y; yv[k][2] = q.z; yv[k][3] = q.w; }
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (x + j < a.dst_w) yv[k][j] = yr[j];
-                }
-            }
-        }
-    }
-    // (2) the horizontal weights of this thread's four columns
-    int s0[4], n[4];
+    // ---- once per block: the horizontal weights of this thread's four columns.  Taps beyond a column's count are made
+    //      harmless WITHOUT a branch: weight 0.0 and a source address that points at the zero column every mid row ends
+    //      with (0.0 * 0.0 = +0.0, and acc + 0.0 is acc: the accumulator starts at +0.0 and can never become -0.0).  Reading
+    //      a real sample with weight 0 would not do: 0 * inf is NaN, and the reference never touches those samples
+    //      (trailing zero taps are trimmed, src/frawscale.cpp:95-107). ----
+    const float* hp[4][MAXT];                  // LDS address of tap t of column j in mid row `wv` of plane 0
     double w[4][MAXT];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int xc = min(x0t + 4 * lane + j, a.dst_w - 1);
-        s0[j] = a.hfirst[xc] - c0; n[j] = a.htaps[xc];
+        const int s0 = a.hfirst[xc] - c0, n = a.htaps[xc];
         const double* wr = a.hwt + (size_t)xc * a.hstride;
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) w[j][t] = t < n[j] ? wr[t] : 0.0;
-    }
-    // (3) the vertical weights of the tile's rows
-    if (tid < TH * MAXT) {
-        const int r = tid / MAXT, t = tid - r * MAXT;
-        if (r < rows) {
-            const int y = y0 + r;
-            const int cnt = a.vtaps[y];
-            vw[tid] = t < cnt ? a.vwt[(size_t)y * a.vstride + t] : 0.0;
-            if (t == 0) { vf[r] = a.vfirst[y] - vmin; vn[r] = cnt; }
+        for (int t = 0; t < MAXT; ++t) {
+            w[j][t] = t < n ? wr[t] : 0.0;
+            hp[j][t] = mid + wv * LW + (t < n ? s0 + t : ZC);
         }
     }
-    // (4) the source patch: rows [vmin, vmin+nsrc) x columns [c0, c0+cn), item i = r*cn + c, U independent loads at a time
-    {
-        const int total = nsrc * cn;
-        const int qstep = 256 / cn, rstep = 256 - qstep * cn;      // (r, c) advance of 256 items
-        int r = tid / cn, c = tid - r * cn;
-        for (int base = 0; base < total; base += 256 * U) {
-            float v[U][NP];
-            int ro[U], co[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                ro[u] = r; co[u] = c;
-                if (base + tid + 256 * u < total) rs_load<KIND, D>(a, vmin + r, c0 + c, v[u]);
-                c += rstep; r += qstep;
-                if (c >= cn) { c -= cn; ++r; }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (base + tid + 256 * u < total) {
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) raw[((size_t)p * a.sr + ro[u]) * a.lw + co[u]] = v[u][p];
-                }
-        }
-    }
-    __syncthreads();
-    // ---- vertical pass over (row, source column) items: same products, same order as k_resample_cols ----
-    {
-        const int total = rows * cn;
-        const int qstep = 256 / cn, rstep = 256 - qstep * cn;
-        int r = tid / cn, c = tid - r * cn;
-        for (int i = tid; i < total; i += 256) {
-            const int rb = vf[r], cnt = vn[r];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const float* col = raw + ((size_t)p * a.sr + rb) * a.lw + c;
-                double acc = 0.0;
-                for (int t = 0; t < cnt; ++t) acc = acc + vw[r * MAXT + t] * (double)col[(size_t)t * a.lw];
-                mid[((size_t)p * TH + r) * a.lw + c] = (float)acc;
-            }
-            c += rstep; r += qstep;
-            if (c >= cn) { c -= cn; ++r; }
-        }
-    }
-    __syncthreads();
-    // ---- horizontal pass (same as k_resample_rows_reg), four columns per lane, then the sink ----
+    if (tid < NP * TH) mid[tid * LW + ZC] = 0.f;                 // the zero column (never overwritten: cn < LW)
+
     const int x = x0t + 4 * lane;
-    if (x >= a.dst_w) return;
+    for (int sub = 0; sub < a.tpb; ++sub) {
+        const int ry0 = (blockIdx.y * a.tpb + sub) * TH;
+        if (ry0 >= a.dst_rows) break;
+        const int rows = min(TH, a.dst_rows - ry0);
+        const int y0 = a.dst_row0 + ry0, yl = y0 + rows - 1;
+        const int vmin = a.vfirst[y0], nsrc = a.vfirst[yl] + a.vtaps[yl] - vmin;     // closed-form row span
+
+        // ---- everything this tile needs from global memory is requested now ----
+        // (1) KIND 2: the Y' values this thread will merge with
+        float yv[RPT][4];
+        if constexpr (KIND == 2) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int r = wv + 4 * k;
-        if (r >= rows) break;
-        float o[NP][4];
+            for (int k = 0; k < RPT; ++k) {
+                const int r = wv + 4 * k;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const float* in = mid + ((size_t)p * TH + r) * a.lw;
+                for (int j = 0; j < 4; ++j) yv[k][j] = 0.f;
+                if (r < rows && x < a.dst_w) {
+                    const float* yr = a.yp + (size_t)(ry0 + r) * a.dst_w + x;
+                    if (a.vec) { const float4 q = *reinterpret_cast<const float4*>(yr); yv[k][0] = q.x; yv[k][1] = q.y; yv[k][2] = q.z; yv[k][3] = q.w; }
+                    else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double acc = 0.0;
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t)
-                    if (t < n[j]) acc = acc + w[j][t] * (double)in[s0[j] + t];
-                o[p][j] = (float)acc;
+                        for (int j = 0; j < 4; ++j) if (x + j < a.dst_w) yv[k][j] = yr[j];
+                    }
+                }
             }
         }
-        const size_t pix = (size_t)(ry0 + r) * a.dst_w + x;
-        if constexpr (KIND != 2) {
-            float* dr = a.dst + pix;
-            if (a.vec) *reinterpret_cast<float4*>(dr) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (x + j < a.dst_w) dr[j] = o[0][j];
+        // (2) the vertical weights of the tile's rows
+        if (tid < TH * MAXT) {
+            const int r = tid / MAXT, t = tid - r * MAXT;
+            if (r < rows) {
+                const int y = y0 + r;
+                const int cnt = a.vtaps[y];
+                vw[tid] = t < cnt ? a.vwt[(size_t)y * a.vstride + t] : 0.0;
+                if (t == 0) { vf[r] = a.vfirst[y] - vmin; vn[r] = cnt; }
             }
-        } else {
-            unsigned char px[4][4];
-            unsigned cw = 0;
+        }
+        // (3) the source patch: rows [vmin, vmin+nsrc) x columns [c0, c0+cn), item i = r*cn + c, U independent loads at a time
+        {
+            const int total = nsrc * cn;
+            const int qstep = 256 / cn, rstep = 256 - qstep * cn;      // (r, c) advance of 256 items
+            int r = tid / cn, c = tid - r * cn;
+            for (int base = 0; base < total; base += 256 * U) {
+                float v[U][NP];
+                int ro[U], co[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float fy = yv[k][j], cb = o[0][j] - 128.f, cr = o[1][j] - 128.f;     // src/libsrcnn.cpp:289-299
-                px[j][0] = to_u8_sat(fy + 45.f * cr / 32.f);
-                px[j][1] = to_u8_sat(fy - (11.f * cb + 23.f * cr) / 32.f);
-                px[j][2] = to_u8_sat(fy + 113.f * cb / 64.f);
-                px[j][3] = 0;
-                if constexpr (D == 4) px[j][3] = to_u8_sat(o[NP - 1][j]);
-                cw |= (unsigned)(unsigned char)fy << (8 * j);                              // src/libsrcnn.cpp:897-901
-            }
-            unsigned char* orow = a.out_rgb + pix * D;
-            if (a.vec) {
-                unsigned wds[D] = {};
+                for (int u = 0; u < U; ++u) {
+                    ro[u] = r; co[u] = c;
+                    if (base + tid + 256 * u < total) rs_load<KIND, D>(a, vmin + r, c0 + c, v[u]);
+                    c += rstep; r += qstep;
+                    if (c >= cn) { c -= cn; ++r; }
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int u = 0; u < U; ++u)
+                    if (base + tid + 256 * u < total) {
 #pragma unroll
-                    for (int ch = 0; ch < D; ++ch) {
-                        const int byte = j * D + ch;
-                        wds[byte >> 2] |= (unsigned)px[j][ch] << (8 * (byte & 3));
-                    }
-                unsigned* o32 = reinterpret_cast<unsigned*>(orow);
-#pragma unroll
-                for (int q = 0; q < D; ++q) o32[q] = wds[q];
-                if constexpr (CONV) *reinterpret_cast<unsigned*>(a.out_conv + pix) = cw;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x + j < a.dst_w) {
-#pragma unroll
-                        for (int ch = 0; ch < D; ++ch) orow[j * D + ch] = px[j][ch];
-                        if constexpr (CONV) a.out_conv[pix + j] = (unsigned char)(cw >> (8 * j));
+                        for (int p = 0; p < NP; ++p) raw[p * raw_plane + ro[u] * LW + co[u]] = v[u][p];
                     }
             }
         }
+        __syncthreads();
+        // ---- vertical pass: a wave takes one tile row at a time (first source row, tap count and weights are wave-uniform),
+        //      lanes run over the source columns; the tap count selects a fully unrolled body ----
+        for (int r = wv; r < rows; r += 4) {
+            const int rb = __builtin_amdgcn_readfirstlane(vf[r]), cnt = __builtin_amdgcn_readfirstlane(vn[r]);
+            float* mrow = mid + r * LW;
+            const double* vwr = vw + r * MAXT;
+            switch (cnt) {
+#define RS_V(N) case N: if constexpr (N <= MAXT) rs_vertical_row<N, NP, MAXT, LW>(raw, raw_plane, mrow, vwr, rb, cn, lane); break;
+            RS_V(1) RS_V(2) RS_V(3) RS_V(4) RS_V(5) RS_V(6) RS_V(7) RS_V(8)
+#undef RS_V
+            default: break;
+            }
+        }
+        __syncthreads();
+        // ---- horizontal pass (same as k_resample_rows_reg), four columns per lane, then the sink ----
+        if (x < a.dst_w) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = wv + 4 * k;
+                if (r >= rows) break;
+                float o[NP][4];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float xs[MAXT];
+#pragma unroll
+                        for (int t = 0; t < MAXT; ++t) xs[t] = hp[j][t][(p * TH + 4 * k) * LW];      // immediate offset
+                        double acc = 0.0;
+#pragma unroll
+                        for (int t = 0; t < MAXT; ++t) acc = acc + w[j][t] * (double)xs[t];
+                        o[p][j] = (float)acc;
+                    }
+                }
+                const size_t pix = (size_t)(ry0 + r) * a.dst_w + x;
+                if constexpr (KIND != 2) {
+                    float* dr = a.dst + pix;
+                    if (a.vec) *reinterpret_cast<float4*>(dr) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (x + j < a.dst_w) dr[j] = o[0][j];
+                    }
+                } else {
+                    unsigned char px[4][4];
+                    unsigned cw = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float fy = yv[k][j], cb = o[0][j] - 128.f, cr = o[1][j] - 128.f;     // src/libsrcnn.cpp:289-299
+                        px[j][0] = to_u8_sat(fy + 45.f * cr / 32.f);
+                        px[j][1] = to_u8_sat(fy - (11.f * cb + 23.f * cr) / 32.f);
+                        px[j][2] = to_u8_sat(fy + 113.f * cb / 64.f);
+                        px[j][3] = 0;
+                        if constexpr (D == 4) px[j][3] = to_u8_sat(o[NP - 1][j]);
+                        cw |= (unsigned)(unsigned char)fy << (8 * j);                              // src/libsrcnn.cpp:897-901
+                    }
+                    unsigned char* orow = a.out_rgb + pix * D;
+                    if (a.vec) {
+                        unsigned wds[D] = {};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int ch = 0; ch < D; ++ch) {
+                                const int byte = j * D + ch;
+                                wds[byte >> 2] |= (unsigned)px[j][ch] << (8 * (byte & 3));
+                            }
+                        unsigned* o32 = reinterpret_cast<unsigned*>(orow);
+#pragma unroll
+                        for (int q = 0; q < D; ++q) o32[q] = wds[q];
+                        if constexpr (CONV) *reinterpret_cast<unsigned*>(a.out_conv + pix) = cw;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (x + j < a.dst_w) {
+#pragma unroll
+                                for (int ch = 0; ch < D; ++ch) orow[j * D + ch] = px[j][ch];
+                                if constexpr (CONV) a.out_conv[pix + j] = (unsigned char)(cw >> (8 * j));
+                            }
+                    }
+                }
+            }
+        }
+        __syncthreads();                       // the next tile overwrites raw / mid / vw
     }
 }
 
@@ -1273,43 +1320,84 @@ bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int 
 static inline bool aligned_to(const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 namespace {
-struct Rs2dPlan { int lw = 0, sr = 0, maxt = 0, th = 16; size_t lds = 0; unsigned gx = 0, gy = 0; bool ok = false; };
+constexpr int RS_LDS_LIMIT = 96 * 1024;        // dynamic LDS a k_rs2d launch may ask for (rs2d_prepare raises the 64 KB default)
+
+struct Rs2dPlan { int lw = 0, sr = 0, maxt = 0, tpb = 1; size_t lds = 0; unsigned gx = 0, gy = 0; bool ok = false; };
 
 // Tile spans of one launch from the tables' host copies (the tables are monotone, so a tile's span is given by its ends).
-Rs2dPlan rs2d_plan(int np, int dst_w, int dst_row0, int dst_rows, const DevAxisTable& tv, const DevAxisTable& th)
+// `sliding`: the caller wants a bound that holds for ANY alignment of the tile rows inside [dst_row0, +dst_rows) (rs2d_fits).
+Rs2dPlan rs2d_plan(int np, int dst_w, int dst_row0, int dst_rows, const DevAxisTable& tv, const DevAxisTable& th, bool sliding = false)
 {
     Rs2dPlan p;
     if (dst_rows <= 0 || dst_w <= 0 || !tv.monotone || !th.monotone || !tv.h_first || !th.h_first) return p;
     const int m = std::max(tv.max_taps, th.max_taps);
     if (m > 8) return p;
-    p.maxt = m <= 4 ? 4 : (m <= 6 ? 6 : 8);
-    static const int th_env = [] { const char* e = getenv("SRCNN_RS_TH"); return e ? atoi(e) : 0; }();
-    p.th = (th_env == 32) ? 32 : 16;
+    p.maxt = m <= 3 ? 3 : (m <= 5 ? 5 : 8);
+    int span = 0;
     for (int x0 = 0; x0 < dst_w; x0 += 256) {
         const int xl = std::min(x0 + 256, dst_w) - 1;
-        p.lw = std::max(p.lw, th.h_first[xl] + th.h_taps[xl] - th.h_first[x0]);
+        span = std::max(span, th.h_first[xl] + th.h_taps[xl] - th.h_first[x0]);
     }
-    for (int r = 0; r < dst_rows; r += p.th) {
-        const int y0 = dst_row0 + r, yl = dst_row0 + std::min(r + p.th, dst_rows) - 1;
+    // LDS row stride (compile-time in the kernel): the tile's source columns + the zero column.  136 covers every ratio >= 2.
+    p.lw = span + 1 <= 136 ? 136 : (span + 1 <= 272 ? 272 : 0);
+    for (int r = 0; r < dst_rows; r += (sliding ? 1 : RS_TH)) {
+        const int y0 = dst_row0 + r, yl = dst_row0 + std::min(r + RS_TH, dst_rows) - 1;
         p.sr = std::max(p.sr, tv.h_first[yl] + tv.h_taps[yl] - tv.h_first[y0]);
     }
-    p.lw = (p.lw + 1) & ~1;
-    p.lds = (size_t)p.th * p.maxt * sizeof(double) + (size_t)p.th * 2 * sizeof(int) + (size_t)np * (p.sr + p.th) * p.lw * sizeof(float);
-    p.gx = cdiv(dst_w, 256); p.gy = cdiv(dst_rows, p.th);
-    p.ok = p.lds <= 64 * 1024 && p.gy <= 65535u && p.lw > 0 && p.sr > 0;
+    p.lds = (size_t)rs_lds_bytes(np, p.maxt, p.sr, p.lw);
+    // a block marches through `tpb` row tiles with its horizontal weights in registers; keep >= ~4 blocks per CU in the grid
+    const unsigned tiles_y = cdiv(dst_rows, RS_TH);
+    p.gx = cdiv(dst_w, 256);
+    static const int tpb_env = [] { const char* e = getenv("SRCNN_RS_TPB"); return e ? atoi(e) : 0; }();
+    // one round of resident blocks where possible (4 blocks per CU x 256 CUs: a grid of 1.1 rounds runs as long as one of 2:
+    // measured 0.088 ms at tpb 7 = 1170 blocks vs 0.075 ms at tpb 8 = 1020 blocks for an 8K plane)
+    p.tpb = tpb_env > 0 ? std::min(tpb_env, RS_MAX_TPB) : (int)std::max(1u, std::min<unsigned>(RS_MAX_TPB, cdiv(p.gx * tiles_y, 1024u)));
+    p.gy = cdiv(tiles_y, p.tpb);
+    p.ok = p.lw > 0 && p.sr > 0 && p.lds <= (size_t)RS_LDS_LIMIT && p.gy <= 65535u;
     return p;
+}
+
+template <int KIND, int D, bool CONV, class F>
+void rs2d_variants(F&& f)
+{
+#define RS_ONE(MT, LW_) f(reinterpret_cast<const void*>(&k_rs2d<KIND, D, MT, LW_, CONV>), MT, LW_);
+    RS_ONE(3, 136) RS_ONE(5, 136) RS_ONE(8, 136) RS_ONE(3, 272) RS_ONE(5, 272) RS_ONE(8, 272)
+#undef RS_ONE
 }
 
 template <int KIND, int D, bool CONV>
 void rs2d_dispatch(const Rs2dPlan& p, const Rs2dArgs& a, hipStream_t s)
 {
     const dim3 grid(p.gx, p.gy), block(256);
-#define RS_GO(MT, TH_) hipLaunchKernelGGL((k_rs2d<KIND, D, MT, TH_, CONV>), grid, block, p.lds, s, a)
-    if (p.th == 32) { if (p.maxt == 4) RS_GO(4, 32); else if (p.maxt == 6) RS_GO(6, 32); else RS_GO(8, 32); }
-    else            { if (p.maxt == 4) RS_GO(4, 16); else if (p.maxt == 6) RS_GO(6, 16); else RS_GO(8, 16); }
+#define RS_GO(MT, LW_) hipLaunchKernelGGL((k_rs2d<KIND, D, MT, LW_, CONV>), grid, block, p.lds, s, a)
+    if (p.lw == 136) { if (p.maxt == 3) RS_GO(3, 136); else if (p.maxt == 5) RS_GO(5, 136); else RS_GO(8, 136); }
+    else             { if (p.maxt == 3) RS_GO(3, 272); else if (p.maxt == 5) RS_GO(5, 272); else RS_GO(8, 272); }
 #undef RS_GO
 }
 }  // namespace
+
+hipError_t rs2d_prepare()
+{
+    hipError_t err = hipSuccess;
+    auto raise = [&](const void* fn, int, int) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_LIMIT);
+        if (e != hipSuccess && err == hipSuccess) err = e;
+    };
+    rs2d_variants<0, 3, false>(raise);
+    rs2d_variants<1, 3, false>(raise); rs2d_variants<1, 4, false>(raise);
+    rs2d_variants<2, 3, false>(raise); rs2d_variants<2, 3, true>(raise);
+    rs2d_variants<2, 4, false>(raise); rs2d_variants<2, 4, true>(raise);
+    return err;
+}
+
+// Would k_rs2d (np = 1: plane resample; np = depth-1: fused colour merge) accept EVERY band inside rows [r0, r1)?  The bound
+// is taken over all alignments of the tile rows, so a yes holds for whatever bands the caller later cuts the range into.
+bool rs2d_fits(int np, int src_w, int src_h, int dst_w, int dst_h, int r0, int r1, const DevAxisTable& tv, const DevAxisTable& th)
+{
+    if (dst_w < src_w || dst_h < src_h || r1 <= r0) return false;
+    const Rs2dPlan p = rs2d_plan(np, dst_w, r0, r1 - r0, tv, th, true);
+    return p.lw > 0 && p.sr > 0 && p.maxt > 0 && p.lds <= (size_t)RS_LDS_LIMIT;
+}
 
 bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
                  const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s)
@@ -1321,7 +1409,7 @@ bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w
     Rs2dArgs a{};
     a.src_plane = src.plane; a.src_rgb = src.rgb; a.src_w = src_w;
     a.dst = dst; a.dst_w = dst_w; a.dst_row0 = dst_row0; a.dst_rows = dst_rows;
-    a.lw = p.lw; a.sr = p.sr;
+    a.sr = p.sr; a.tpb = p.tpb;
     a.vfirst = tv.first; a.vtaps = tv.taps; a.vwt = tv.weight; a.vstride = tv.stride;
     a.hfirst = th.first; a.htaps = th.taps; a.hwt = th.weight; a.hstride = th.stride;
     a.vec = (dst_w % 4 == 0) && aligned_to(dst, 16);
@@ -1342,7 +1430,7 @@ bool launch_merge_fused(const unsigned char* rgb_src, int src_w, int src_h, int 
     a.src_rgb = rgb_src; a.src_w = src_w;
     a.yp = Yp; a.out_rgb = rgb_out; a.out_conv = conv_opt;
     a.dst_w = dst_w; a.dst_row0 = dst_row0; a.dst_rows = dst_rows;
-    a.lw = p.lw; a.sr = p.sr;
+    a.sr = p.sr; a.tpb = p.tpb;
     a.vfirst = tv.first; a.vtaps = tv.taps; a.vwt = tv.weight; a.vstride = tv.stride;
     a.hfirst = th.first; a.htaps = th.taps; a.hwt = th.weight; a.hstride = th.stride;
     a.vec = (dst_w % 4 == 0) && aligned_to(Yp, 16) && aligned_to(rgb_out, 4) && (!conv_opt || aligned_to(conv_opt, 4));

@@ -17,6 +17,7 @@
 // (hipEventSynchronize / condition variable): on this runtime a copy that waits device-side on another queue's event does
 // not overlap that queue's kernels (profiles/r02_stream_overlap.txt), and the round-2 yield() spin loops are gone.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -38,6 +39,18 @@ bool is_pinned(const void* p)
     (void)hipGetLastError();
     return yes;
 }
+
+// The caller's result buffers are fresh new[] blocks (src/libsrcnn.cpp:874-887 hands back new[] memory) whose pages fault
+// in on first touch; with 4 KB pages the fan-out memcpy is fault-bound (100 MB: 6.6-8 ms on 4-8 threads), with transparent
+// huge pages it runs at memory speed (1.5 ms) -- profiles/r03_host_out_probe.txt.  A hint only: harmless where THP is off.
+void hint_huge_pages(void* p, size_t n)
+{
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
+    if (e > a + (4u << 20)) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);
+}
+
+constexpr unsigned kBlockingEvent = hipEventDisableTiming | hipEventBlockingSync;   // host waits sleep, they do not spin
 
 // Start a helper thread; false (and nothing started) if the system refuses -- callers then run the work inline.
 template <class F>
@@ -63,7 +76,7 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
         if (!sl.st && hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
         if (!rc && !sl.cst && hipStreamCreateWithFlags(&sl.cst, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
         for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out})
-            if (!rc && !*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = fail(SRCNN_E_HIP, "event create");
+            if (!rc && !*e && hipEventCreateWithFlags(e, kBlockingEvent) != hipSuccess) rc = fail(SRCNN_E_HIP, "event create");
         if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) {     // shape or mode changed: drop the graph first,
             if (sl.exec) { (void)hipStreamSynchronize(cx.slots[0].st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
             sl.ws.frozen = false;                                          // then its buffers may move again
@@ -176,10 +189,12 @@ std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, bool fi
     const unsigned cap = budget_band_rows(dw);
     std::vector<unsigned> cuts{R0};
     if (rows >= 512) {
-        // 40 % / 30 % / 18 % / 12 % (a share of a multi-context call: 50 / 30 / 20)
-        static const double four[] = {0.40, 0.70, 0.88}, three[] = {0.50, 0.80};
-        const double* f = first_share_of_many ? three : four;
-        const int nf = first_share_of_many ? 2 : 3;
+        // 30 / 30 / 25 / 10 / 5 % (a share of a multi-context call: 45 / 35 / 15 / 5).  Banding itself costs nothing on the
+        // device (profiles/r03_band_probe.txt); the cut points only decide when the first D2H can start and how much is
+        // left to copy after the last kernel.
+        static const double five[] = {0.30, 0.60, 0.85, 0.95}, four[] = {0.45, 0.80, 0.95};
+        const double* f = first_share_of_many ? four : five;
+        const int nf = first_share_of_many ? 3 : 4;
         for (int i = 0; i < nf; ++i) cuts.push_back(R0 + ((unsigned)(rows * f[i]) & ~15u));
     }
     cuts.push_back(R1);
@@ -240,7 +255,11 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if ((rc = get_table(c, J.cfilter, dw, w, ch_))) return rc;
         if ((rc = get_table(c, J.filter, dh, h, yv))) return rc;
         if ((rc = get_table(c, J.filter, dw, w, yh))) return rc;
-        for (const TableRef& t : {cv, ch_, yv, yh}) if (!t->monotone || t->max_taps > 8) fused_shell = false;
+        // every band of this share must be acceptable to both fused kernels (Y from RGB, merge with on-the-fly chroma);
+        // the Y path reads rows up to 6 beyond the share
+        const unsigned ya = R0 >= 6 ? R0 - 6 : 0, yb = std::min(dh, R1 + 6);
+        fused_shell = rs2d_fits(1, (int)w, (int)h, (int)dw, (int)dh, (int)ya, (int)yb, yv->view(), yh->view()) &&
+                      rs2d_fits((int)d - 1, (int)w, (int)h, (int)dw, (int)dh, (int)R0, (int)R1, cv->view(), ch_->view());
     }
 
     // ---- device buffers (the lane's grow-only scratch) ----
@@ -272,7 +291,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     if (!fused_shell && (rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
     while (L.band_events.size() < 2 * nb + 1) {
         hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e, kBlockingEvent));
         L.band_events.push_back(e);
     }
 
@@ -285,6 +304,8 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     } else {
         if ((rc = grow_pinned(cx, L.pin_in, L.pin_in_n, src_bytes))) return rc;
         if ((rc = grow_pinned(cx, L.pin_out, L.pin_out_n, out_bytes + share_px))) return rc;
+        hint_huge_pages(J.out + (size_t)R0 * dw * d, out_bytes);
+        if (J.conv) hint_huge_pages(J.conv + (size_t)R0 * dw, share_px);
         parallel_memcpy(L.pin_in, J.rgb + src_off, src_bytes);
         HIP_TRY(hipMemcpyAsync(d_rgb + src_off, L.pin_in, src_bytes, hipMemcpyHostToDevice, s));
     }
@@ -371,6 +392,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     }
     if (threaded) fanout.join();
     const auto t2 = now();
+    // everything this call queued has completed by now (the helper waited for the last D2H event); these return at once
     hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(L.copy_st);
     if (launch_rc) return launch_rc;
     if (e1 != hipSuccess || e2 != hipSuccess || copy_err) return fail(SRCNN_E_HIP, "pipeline failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
@@ -563,9 +585,9 @@ int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, fl
                                        sizeof(float) * (size_t)(hi - lo) * w, N.st));
             src = N.in;
         }
-        while (N.events.size() < nsub) {
+        while (N.events.size() < nsub + 2) {
             hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&e, kBlockingEvent));
             N.events.push_back(e);
         }
         // sub-bands: the kernels of sub-band i+1 are queued before the host waits for sub-band i and pushes it to the root
@@ -592,8 +614,11 @@ int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, fl
             if (i + 1 < nsub && (r = launch(i + 1))) return r;
             if ((r = push(i))) return r;
         }
-        HIP_TRY(hipStreamSynchronize(N.st));
-        HIP_TRY(hipStreamSynchronize(N.copy_st));
+        // wait for both queues on blocking events (8 workers spinning in hipStreamSynchronize would burn 8 host cores)
+        HIP_TRY(hipEventRecord(N.events[nsub], N.st));
+        HIP_TRY(hipEventRecord(N.events[nsub + 1], N.copy_st));
+        HIP_TRY(hipEventSynchronize(N.events[nsub]));
+        HIP_TRY(hipEventSynchronize(N.events[nsub + 1]));
         return SRCNN_OK;
     };
     std::vector<std::thread> th(nctx);
