@@ -2,6 +2,7 @@
 #   make            -> libsrcnn_amd/lib/libsrcnn_amd.so + libsrcnn_amd/bin/srcnntest
 #   make oracle     -> the CPU checker (and oracle/_ref where the reference tree is present)
 #   make test       -> CPU test-suite;  make gpu-test on a gfx950 box
+#   make ubench     -> tools/ubench/bin/* (microbenchmarks; hipcc, gfx950)
 #   make asan tsan  -> the host code (table builder, drop-in control flow, oracle) under ASan+UBSan / TSan, CPU only
 HIPCC   ?= /opt/rocm/bin/hipcc
 CSRC    := libsrcnn_amd/csrc
@@ -33,6 +34,16 @@ $(BINDIR)/srcnntest: tools/srcnntest.cpp $(LIBDIR)/libsrcnn_amd.so
 	@mkdir -p $(BINDIR)
 	g++ -O2 -std=c++17 $< -L$(LIBDIR) -lsrcnn_amd -Wl,-rpath,$(abspath $(LIBDIR)) -Wl,-rpath,'$$ORIGIN/../lib' -o $@
 
+# the microbenchmarks behind profiles/r0x_*.txt (outputs are NOT tracked: tools/ubench/bin/ is git-ignored)
+UBENCH_HIP := $(wildcard tools/ubench/*.hip) $(wildcard tools/ubench/*.cpp)
+ubench: $(patsubst tools/ubench/%,tools/ubench/bin/%,$(basename $(UBENCH_HIP)))
+tools/ubench/bin/%: tools/ubench/%.hip
+	@mkdir -p tools/ubench/bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $< -o $@
+tools/ubench/bin/%: tools/ubench/%.cpp
+	@mkdir -p tools/ubench/bin
+	$(HIPCC) --offload-arch=gfx950 -O2 -std=c++17 -x hip $< -o $@ -lpthread
+
 oracle:
 	$(MAKE) -C oracle all
 	@if [ -d /root/reference/src ]; then $(MAKE) -C oracle ref; fi
@@ -62,6 +73,6 @@ tsan: tests/host/_build/host_tsan
 	TSAN_OPTIONS=halt_on_error=1 $<
 
 clean:
-	rm -rf $(LIBDIR) $(BINDIR) oracle/_build oracle/_ref tests/host/_build
+	rm -rf $(LIBDIR) $(BINDIR) oracle/_build oracle/_ref tests/host/_build tools/ubench/bin
 
-.PHONY: all oracle test gpu-test clean asan tsan
+.PHONY: all oracle test gpu-test clean asan tsan ubench

@@ -496,15 +496,24 @@ def dry_run_line(args, rank, world, dist):
 
 def traffic_record():
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc cannot run inside
-    this process), with where it came from, so a stale figure is visible as such."""
-    for name in ("r02_pmc_conv12.json", "pmc_conv12.json"):
+    this process), with where it came from.  The profile records the sha256 of the kernel's source text; if the kernel in
+    this tree is a different text, the figure is withheld (null) and the reason is given instead of a stale number."""
+    from libsrcnn_amd import build as _b
+    now = _b.kernel_source_sha("k_conv12_mfma")
+    for name in ("r03_pmc_conv12.json", "r02_pmc_conv12.json", "pmc_conv12.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
                 rec = json.load(open(path))
-                return rec.get("hbm_bytes_per_launch"), "profiles/%s (%s)" % (name, rec.get("measured_at", "round 1, commit e142cbb"))
             except Exception:
-                pass
+                continue
+            src = "profiles/%s (%s)" % (name, rec.get("measured_at", "round 1, commit e142cbb"))
+            then = rec.get("kernel_source_sha256")
+            if then is None:
+                return None, src + " -- WITHHELD: that profile does not say which kernel text it measured"
+            if then != now:
+                return None, src + " -- WITHHELD: k_conv12_mfma has changed since (re-run tools/collect_profiles.sh)"
+            return rec.get("hbm_bytes_per_launch"), src
     return None, None
 
 

@@ -34,11 +34,43 @@ def hipcc():
     return "hipcc"
 
 
+STAMP = os.path.join(LIBDIR, "build.sha256")
+
+
+def source_digest():
+    """sha256 over the CONTENT of every input of the build (sources, headers, this recipe, the flags): a prebuilt .so that
+    travelled with a snapshot can therefore never mask sources that changed under it, whatever the file times say."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    for d in sorted(set(DEPS)) + [os.path.abspath(__file__)]:
+        path = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS) or os.path.getmtime(__file__) > t
+    try:
+        return open(STAMP).read().strip() != source_digest()
+    except OSError:
+        return True
+
+
+def kernel_source_sha(name="k_conv12_mfma"):
+    """sha256 of the source text of one kernel (from its template header to the next banner comment): profiles that quote a
+    counter for that kernel record it, and bench.py refuses to quote a counter taken from a different kernel text."""
+    import hashlib
+    import re
+    src = open(os.path.join(CSRC, "srcnn_kernels.hip")).read()
+    m = re.search(r"template <[^>]*>\s*__global__[^\n]*void %s\(" % re.escape(name), src)
+    if not m:
+        return None
+    end = src.find("// ====", m.end())
+    return hashlib.sha256(src[m.start():end if end > 0 else len(src)].encode()).hexdigest()
 
 
 def build(force=False, verbose=True):
@@ -58,6 +90,8 @@ def build(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     build_cli(verbose)
+    with open(STAMP, "w") as f:
+        f.write(source_digest() + "\n")
     return LIB
 
 

@@ -75,7 +75,9 @@ if pmc:
     if k12 and "FETCH_SIZE" in k12 and "WRITE_SIZE" in k12:
         n_out = 7680 * 4320
         fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024
-        rec = {"kernel": "k_conv12_mfma", "tag": tag, "measured_at": "tools/collect_profiles.sh %s, code at commit %s" % (tag, head),
+        sys.path.insert(0, ROOT)
+        from libsrcnn_amd import build as _b
+        rec = {"kernel": "k_conv12_mfma", "tag": tag, "kernel_source_sha256": _b.kernel_source_sha("k_conv12_mfma"), "measured_at": "tools/collect_profiles.sh %s, code at commit %s" % (tag, head),
                "fetch_bytes": fetch, "write_bytes": write,
                "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 132 * n_out,
                "note": "FETCH_SIZE/WRITE_SIZE are KiB, separate passes.  The guide's x2 FETCH correction is for 16 B/lane streams; "
