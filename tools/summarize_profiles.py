@@ -34,6 +34,9 @@ def short(name):
         tier = " [strict]"
     elif "<false" in name:
         tier = " [fast tier]"
+    if "k_rs2d<" in name:
+        kind = name.split("k_rs2d<")[1].split(",")[0].strip()
+        return {"0": "k_rs2d [plane -> plane]", "1": "k_rs2d [RGB -> upscaled Y]", "2": "k_rs2d [fused chroma resample + colour merge]"}.get(kind, "k_rs2d")
     for key in ("k_fused_f16", "k_conv12_f16", "k_conv12_mfma", "k_conv12", "k_conv3_fast", "k_conv3", "k_resample_2d", "k_resample_rows", "k_resample_cols", "k_rgb_split",
                 "k_ycc_merge"):
         if key in name:
@@ -98,3 +101,38 @@ if b and os.path.getsize(b):
     lines.append("\n## bench line of the same build (`%s_bench.json`)\n\n```\n%s```" % (tag, open(b).read()))
 open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+
+# ---- ProcessSRCNN (tools/profile_process.sh): the colour shell + the banded Y path as ONE call runs them ----
+pstats = one("process_kt/**/*_kernel_stats.csv")
+if pstats:
+    shutil.copy(pstats, os.path.join(dst, tag + "_process_kernel_stats.csv"))
+    ppmc = {}
+    for which in ("fetch", "write"):
+        f = one("process_%s/**/*_counter_collection.csv" % which)
+        if f:
+            shutil.copy(f, os.path.join(dst, "%s_process_pmc_%s.csv" % (tag, which)))
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                ppmc.setdefault(k, {})[which] = sum(v) / len(v)
+    pl = ["# ProcessSRCNN(3840x2160 RGB, x2) on MI355X, `%s` (code at commit %s)\n" % (tag, head),
+          "`rocprofv3 --kernel-trace --stats -- python3 tools/process_probe.py --reps 4`; FETCH_SIZE / WRITE_SIZE from separate "
+          "`--pmc` passes, KiB per launch as rocprofv3 reports them (one launch = one band of the output).\n",
+          "| kernel | launches | avg ms | total ms | % | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch |", "|---|---|---|---|---|---|---|"]
+    calls = 4.0
+    per_call = collections.OrderedDict()
+    for r in csv.DictReader(open(pstats)):
+        k = short(r["Name"])
+        pm = ppmc.get(k, {})
+        pl.append("| %s | %s | %.4f | %.2f | %s | %.0f | %.0f |" % (k, r["Calls"], float(r["AverageNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6,
+                                                              r["Percentage"], pm.get("fetch", float("nan")), pm.get("write", float("nan"))))
+        per_call[k] = float(r["TotalDurationNs"]) / 1e6 / calls
+    pl.append("\nDevice time per call: " + ", ".join("%s %.2f ms" % kv for kv in per_call.items()) + " = %.2f ms." % sum(per_call.values()))
+    shell = sum(v for k, v in per_call.items() if "k_rs2d" in k or "split" in k or "merge" in k or "resample" in k)
+    pl.append("Colour shell + resamplers (everything that is not a convolution layer): %.2f ms per call." % shell)
+    wj = one("process_wall.json")
+    if wj:
+        pl.append("\nWall time of the call, un-profiled (`tools/process_probe.py --reps 8`): `%s`" % open(wj).read().strip())
+    open(os.path.join(dst, tag + "_process_summary.md"), "w").write("\n".join(pl) + "\n")
+    print("\n".join(pl))
