@@ -991,11 +991,18 @@ __global__ __launch_bounds__(256) void k_conv3(
     float* __restrict__ out, int out_row0, int out_rows)
 {
     __shared__ float tile[2][C3_MC * C3_CH];
+    __shared__ __attribute__((aligned(16))) float w3s[C2N * 30];   // [m][dy][6]: (w0,w1) (w2,w3) w4 pad -- packed-operand order
 
     const int tx0 = blockIdx.x * C3_TW;
     const int ty0 = out_row0 + blockIdx.y * C3_TH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c2_last = c2_row_base + c2_rows - 1;
+    if constexpr (STRICT) {
+        for (int e = tid; e < C2N * 30; e += 256) {
+            const int m = e / 30, k = e - m * 30, dy = k / 6, dx = k - dy * 6;
+            w3s[e] = dx < 5 ? cW.w3[m][dy * 5 + dx] : 0.f;
+        }
+    }
 
     // staging geometry (fixed per thread)
     const int bx = min(tx0 + lane, W - 1);                                  // body column
@@ -1049,32 +1056,55 @@ __global__ __launch_bounds__(256) void k_conv3(
 #pragma unroll 1
         for (int m = 0; m < C3_MC; ++m) {
             const float* t = cur + m * C3_CH + (wv * 4) * C3_LW + lane;
-            const float* wm = cW.w3[c * C3_MC + m];
-            float win[8][5];
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 5; ++cc) win[r][cc] = t[r * C3_LW + cc];
             if constexpr (STRICT) {
+                // Products two at a time (v_pk_mul_f32) with BOTH operands already sitting in register pairs: the window
+                // row as (c0,c1) (c2,c3) c4 straight from ds_read2_b32, the channel's weights in the same shape from the
+                // block's LDS copy (uniform address -> broadcast read).  Round 2 took the weights from SGPRs, which cost
+                // a v_mov_b32 per packed operand (53 of 317 VALU instructions per channel).  Measured: the same 2.31 ms per
+                // 8K frame with or without them -- the pace is set by the 104 v_cvt_f64_f32 + 100 v_add_f64 + 50
+                // v_pk_mul_f32 per channel at their measured issue rates (4.4 / 5.5 / 4.4 cycles, profiles/r01_valu_rates.txt:
+                // 1305 cycles per wave-channel predicted, 1298 measured); the movs rode in their shadow.  2-channel stages
+                // with 4 waves per SIMD: 2.48 ms (more barriers, spills).
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 va[8], vb[8];
+                float vc[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    va[r] = f2{t[r * C3_LW + 0], t[r * C3_LW + 1]};
+                    vb[r] = f2{t[r * C3_LW + 2], t[r * C3_LW + 3]};
+                    vc[r] = t[r * C3_LW + 4];
+                }
+                const float* wrow = w3s + (c * C3_MC + m) * 30;
                 // four independent fp64 chains (one per pixel) advance tap by tap, so consecutive v_add_f64 never
                 // depend on each other
                 double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int dy = 0; dy < 5; ++dy)
+                for (int dy = 0; dy < 5; ++dy) {
+                    const f2 wa = f2{wrow[dy * 6 + 0], wrow[dy * 6 + 1]};
+                    const f2 wb = f2{wrow[dy * 6 + 2], wrow[dy * 6 + 3]};
+                    const float wc = wrow[dy * 6 + 4];
 #pragma unroll
-                    for (int dx = 0; dx < 5; ++dx) {
-                        const float wv_ = wm[dy * 5 + dx];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float pr = wv_ * win[q + dy][dx];
-                            // tap 0: "0.0 + p" is p (a -0 differs from the reference's +0 only until it is folded
-                            // into the fp32 running sum, which can never be -0)
-                            a[q] = (dy == 0 && dx == 0) ? (double)pr : a[q] + (double)pr;
-                        }
+                    for (int q = 0; q < 4; ++q) {
+                        const f2 pa = wa * va[q + dy], pb = wb * vb[q + dy];
+                        const float pc = wc * vc[q + dy];
+                        // tap (0,0): "0.0 + p" is p (a -0 differs from the reference's +0 only until it is folded
+                        // into the fp32 running sum, which can never be -0)
+                        a[q] = (dy == 0) ? (double)pa.x : a[q] + (double)pa.x;
+                        a[q] = a[q] + (double)pa.y;
+                        a[q] = a[q] + (double)pb.x;
+                        a[q] = a[q] + (double)pb.y;
+                        a[q] = a[q] + (double)pc;
                     }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sum[q] = (float)((double)sum[q] + a[q]);
             } else {
+                const float* wm = cW.w3[c * C3_MC + m];
+                float win[8][5];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 5; ++cc) win[r][cc] = t[r * C3_LW + cc];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float a = 0.f;
