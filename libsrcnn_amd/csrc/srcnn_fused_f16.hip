@@ -37,6 +37,11 @@
 // no barrier in the main loop, so the two waves that share a SIMD can sit in different phases -- one in the MFMA-only
 // layer-1 phase while the other does the VALU-heavy layer-2/3 hand-offs -- instead of marching in lockstep.
 //
+// Round 3: the slot layout is [hi0 | lo0 | hi1 | lo1] with copy 1 shifted by -1, which puts the even lanes' fragment reads on
+// banks 0-15 and the odd lanes' on banks 16-31 of a ds_read_b32 lane group; round 2's [hi0 | hi1 | lo0 | lo1] with a +1 shift
+// had them overlap on 7 banks, a 2-way conflict on every layer-1 fragment read (SQ_LDS_BANK_CONFLICT 7.4e7 -> 1.7e6 cycles
+// per 8K frame, 20 % -> 0.6 % of the LDS-active cycles; kernel 1.53 -> 1.42 ms; profiles/r03_fused_bank_conflicts.txt).
+//
 // LDS (NW = 8): weight fragments + biases 48.4 KB + Y rings 60 KB + P buffers 50 KB = 158.4 KB -> one workgroup per
 // CU, two waves per SIMD.  HBM traffic: 4 B in + 4 B out per pixel (+ 6.7 % / chunk-halo re-reads, all L2 hits).
 //
@@ -81,7 +86,7 @@ constexpr int OW = 32 * SEG - 4;                 // output columns per wave
 constexpr int GW = NW * OW;                      // output columns per workgroup
 constexpr int TWW = 32 * SEG + 8;                // staged Y columns per wave: the layer-2 columns +-4
 constexpr int PB = 2 * (TWW + 8);                // bytes per ring plane row: TWW + 1 (shifted copy) + 7 halves
-constexpr int SB = 4 * PB;                       // bytes per ring slot: planes hi0, hi1 (shifted), lo0, lo1 (shifted)
+constexpr int SB = 4 * PB;                       // bytes per ring slot: planes hi0, lo0, hi1 (shifted), lo1 (shifted)
 constexpr int SLOTS = 12, STAGE = 4;             // ring rows / rows per stage (SLOTS = STAGE + 8 halo rows)
 constexpr int RING = SLOTS * SB;                 // bytes per wave
 constexpr int PS = 32 * SEG;                     // P plane stride (floats)
@@ -213,8 +218,12 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                 _Float16 hi, lo;
                 split_f16(pre[k], hi, lo);
                 _Float16* row = reinterpret_cast<_Float16*>(Yr + (slot0 + r) * SB);
-                row[t] = hi;                      row[PB / 2 + t + 1] = hi;          // copy 1 holds column t at t + 1
-                row[PB + t] = lo;                 row[3 * PB / 2 + t + 1] = lo;
+                // Slot layout [hi0 | lo0 | hi1 | lo1]; copy 1 holds column t at t - 1.  A B fragment starts at column q0 of copy
+                // q0 & 1, so even lanes 2k read dword k of copy 0 and odd lanes 2k+1 dword 2*PB/4 + k = 80 + k of copy 1: banks
+                // [0,16) and [16,32) of the 32 a ds_read_b32 lane group sees -- disjoint.  (Round 2 had copy 1 at +PB with a +1
+                // shift: dword 41 + k, banks 9..24, a 2-way conflict on every layer-1 fragment read: 20 % of all LDS cycles.)
+                row[t] = hi;                      row[PB / 2 + t] = lo;
+                if (t >= 1) { row[PB + t - 1] = hi; row[3 * PB / 2 + t - 1] = lo; }
             }
         }
     };
@@ -237,10 +246,10 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
     const int ox = cx0 + lane;                                  // output column of this lane
     const bool ox_ok = lane >= 2 && lane < 2 + OW && ox < W;
     // LDS byte address (inside a ring slot) of this lane's B fragment for segment 0: staged column q0, from the copy
-    // whose alignment suits its parity; segment 1 is +64 B, the lo plane +2*PB.  Kept opaque so that every read below
+    // whose alignment suits its parity; segment 1 is +64 B, the lo plane +PB.  Kept opaque so that every read below
     // is "one base register + immediate offset".
     const int q0 = col;
-    unsigned frag_hi = (unsigned)(L_Y + wv * RING + ((q0 & 1) ? PB + 2 * (q0 + 1) : 2 * q0));
+    unsigned frag_hi = (unsigned)(L_Y + wv * RING + ((q0 & 1) ? 2 * PB + 2 * (q0 - 1) : 2 * q0));
     unsigned frag_el = (unsigned)(L_Y + wv * RING + 2 * q0);     // element-wise reads: unshifted copy, any alignment
     asm volatile("" : "+v"(frag_hi), "+v"(frag_el));
 
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                 // window rows 2s (lanes 0-31) and 2s+1 (lanes 32-63), taps dx = 0..7: 8 consecutive halves of one row
                 const unsigned off = (unsigned)((half ? wrap(2 * s + 1) : wrap(2 * s)) * SB);
                 const unsigned* yh = reinterpret_cast<const unsigned*>(lds_raw + (frag_hi + off));
-                const unsigned* yl = yh + 2 * PB / 4;
+                const unsigned* yl = yh + PB / 4;
 #pragma unroll
                 for (int g = 0; g < SEG; ++g) {
                     u32x4 hi4, lo4;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                     const unsigned adr = frag_el + (unsigned)(half ? wrap(j) * SB + 16 : wrap(8) * SB + 2 * j);
                     const _Float16* e = reinterpret_cast<const _Float16*>(lds_raw + adr);
 #pragma unroll
-                    for (int g = 0; g < SEG; ++g) { xbh[g][j] = e[32 * g]; xbl[g][j] = e[32 * g + PB]; }
+                    for (int g = 0; g < SEG; ++g) { xbh[g][j] = e[32 * g]; xbl[g][j] = e[32 * g + PB / 2]; }
                 }
             }
             x0h = *reinterpret_cast<const h8*>(W1f + (((s * 2 + 0) * 2 + 0) * 64 + lane) * 8);
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(NT) void k_fused_f16(
                 const f32x16 w88 = *reinterpret_cast<const f32x16*>(W88s + half * 32 + 16 * blk);
 #pragma unroll
                 for (int g = 0; g < SEG; ++g) {
-                    const float y88 = (float)e88[32 * g] + (float)e88[32 * g + PB];
+                    const float y88 = (float)e88[32 * g] + (float)e88[32 * g + PB / 2];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c1b[g][blk][r] = __builtin_fmaf(w88[r], y88, bias[r]);
                 }
