@@ -149,9 +149,16 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
         if (use_graph && sl.exec) {
             if (hipGraphLaunch(sl.exec, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
         } else {
-            if (sl.exec && sl.ws.frozen) {
-                // an eager call on a slot that still holds a graph of this shape: the graph (and the frozen workspace
-                // and table references it needs) stays valid, the eager run uses the same buffers
+            if (sl.exec) {
+                // an eager call (use_graph == 0) on a slot that still holds a captured graph of this shape: retire the graph
+                // first.  Its workspace is frozen (pointers baked in), so an eager run that needs more scratch -- a larger
+                // srcnn_set_workspace_limit since the capture -- could not grow it; and nothing should keep a graph alive
+                // that the caller no longer asks for.  The next use_graph call captures again after one eager frame.
+                (void)hipStreamSynchronize(ks);
+                (void)hipGraphExecDestroy(sl.exec);
+                sl.exec = nullptr;
+                sl.ws.frozen = false;
+                sl.graph_tables.clear();
             }
             if (sl.tables.size() > 16) sl.tables.clear();   // eager runs re-take their references every frame
             rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);

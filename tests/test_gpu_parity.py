@@ -535,3 +535,50 @@ def test_whole_1080p_frame_against_the_compiled_reference(srcnn):
     want = eng.y_path(y)
     got = srcnn.y_upscale2x(y)
     assert_bit_equal(got, want, "whole 1080p frame, seed %d" % seed)
+
+
+def test_stream_graph_then_eager_with_a_larger_workspace_limit(srcnn):
+    """a use_graph=0 call that follows a use_graph=1 call of the same shape must not trip over the graph's frozen
+    workspace when the scratch limit has been raised in between, must not leave a graph replaying freed tables, and a later
+    use_graph=1 call must still work.  Every variant gives the single-frame results."""
+    S, L = srcnn, srcnn.lib()
+    fr = synth.frames(5, 300, 200, 555, "noise")
+    want = np.stack([S.y_upscale2x(f) for f in fr])
+    prev = L.srcnn_set_workspace_limit(1 << 20)             # tiny: the captured graph bands the frame in 16-row pieces
+    try:
+        a = S.y_upscale2x_stream(fr, use_graph=True)
+        L.srcnn_set_workspace_limit(8 << 30)                # now one band needs far more scratch than the frozen workspace has
+        b = S.y_upscale2x_stream(fr, use_graph=False)
+        # churn the table cache while no graph holds references, then replay through a fresh capture
+        for k in range(70):
+            S.resample(fr[0][:8, :8], 9 + k, 9 + (k % 5), S.SRCNNF_Bilinear)
+        c = S.y_upscale2x_stream(fr, use_graph=True)
+        d = S.y_upscale2x_stream(fr, use_graph=True)
+    finally:
+        L.srcnn_set_workspace_limit(prev)
+    for name, got in (("graph", a), ("eager after graph", b), ("graph again", c), ("replay", d)):
+        assert_bit_equal(got, want, name)
+
+
+def test_trim_gives_memory_back_and_everything_still_works(srcnn, oracle_lib):
+    """srcnn_trim(): idle ProcessSRCNN lanes drop their scratch and page-locked staging, unreferenced contribution tables
+    are evicted; the next calls rebuild what they need and give the same bytes."""
+    import ctypes as C
+    S, L = srcnn, srcnn.lib()
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (700, 1100, 3), dtype=np.uint8)
+    want_rgb, want_conv = oracle_lib.process(img, 2.0)
+    got_rgb, got_conv = S.process_u8(img, 2.0)
+    assert np.array_equal(got_rgb, want_rgb)
+    t0, l0 = C.c_int(), C.c_int()
+    L.srcnn_debug_counts(C.byref(t0), C.byref(l0))
+    assert t0.value >= 2 and l0.value >= 1
+    assert L.srcnn_trim() == 0
+    t1 = C.c_int()
+    L.srcnn_debug_counts(C.byref(t1), None)
+    assert t1.value < t0.value                               # the tables of the call above were unreferenced: evicted (a stream
+                                                             # slot or a live graph may still hold others)
+    got_rgb, got_conv = S.process_u8(img, 2.0)
+    assert np.array_equal(got_rgb, want_rgb) and np.array_equal(got_conv, want_conv)
+    y = synth.plane(33, 47, 9, "noise")
+    assert_bit_equal(S.y_upscale2x(y), oracle_lib.y_path(y), "after trim")
