@@ -217,7 +217,11 @@ __global__ __launch_bounds__(R2_TW) void k_resample_2d(
 // LDS (dynamic): vertical weights, then per plane the source patch [sr][LW] and the intermediate rows [16][LW] (fp32,
 // i.e. rounded after the vertical pass like the reference's intermediate image).  sr is the largest row span any tile of
 // THIS launch has, computed on the host from the table's host copy.  Measured (8K plane, 166 MB): 0.075 ms = 2.2 TB/s
-// (round 2: 0.153 ms); the kernel is VALU-bound on its ~60 instructions per output sample, 3 of 5 of them fp64.
+// (round 2: 0.153 ms).  44 VALU instructions per output sample (3 of 5 of them fp64) keep the SIMDs busy 55 % of the time
+// at 4 waves per SIMD (110 VGPRs); the rest is exposed latency around the two barriers of a tile.  Prefetching the next
+// tile's patch into registers while the current tile computes was tried and is SLOWER (0.088 ms: the 9 extra values per
+// plane push the kernel to 168 VGPRs = 3 waves per SIMD; capped at 128 VGPRs it spills, 0.091 ms) -- occupancy hides the
+// latency better than software pipelining does here.
 // =============================================================================================
 struct Rs2dArgs {
     const float* src_plane; const unsigned char* src_rgb; int src_w;
