@@ -436,8 +436,10 @@ def side_workload(args):
         mpix_step = world * F * 4 * w * h / 1e6
         label = "batch of 64 resident 1920x1080 frames per rank per step"
 
+    comm_made = args.workload == "tiled8k"
     if args.workload != "tiled8k" and world > 1:
         extra["rccl_ranks"], note = rccl_probe(S, dist, rank, world, ndev)
+        comm_made = extra["rccl_ranks"] is not None
         if note:
             extra["rccl_note"] = note
 
@@ -466,7 +468,8 @@ def side_workload(args):
     barrier()
     if cleanup is not None:
         cleanup()
-    L.srcnn_comm_destroy()
+    if comm_made:                          # never after a probe that timed out: its helper thread may still sit inside RCCL
+        L.srcnn_comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -705,8 +708,13 @@ def main():
         print(json.dumps(out), flush=True)
 
     barrier()
+    if world > 1 and rccl_ranks is not None:
+        L.srcnn_comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
+    if world > 1 and rccl_ranks is None and rccl_note and "did not finish" in rccl_note:
+        sys.stdout.flush()
+        os._exit(0)                        # a helper thread is wedged inside RCCL: do not let interpreter shutdown wait for it
 
 
 if __name__ == "__main__":

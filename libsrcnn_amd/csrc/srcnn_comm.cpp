@@ -253,6 +253,21 @@ int srcnn_band_rows(unsigned out_h, int rank, int nranks, unsigned* row0, unsign
     return SRCNN_OK;
 }
 
+// Piece `piece` of `npieces` of rank's band: rows [*row0, *row0 + *rows) of the out_h output rows.  The pieces of a band
+// partition it, the bands partition the frame; every rank derives the same table from (out_h, nranks, npieces) alone, which
+// is what keeps the per-piece gathers of srcnn_comm_tiled_y_upscale2x_f32_dev consistent without any exchange.
+int srcnn_tiled_piece(unsigned out_h, int rank, int nranks, int piece, int npieces, unsigned* row0, unsigned* rows)
+{
+    unsigned b0 = 0, bn = 0;
+    if (int rc = srcnn_band_rows(out_h, rank, nranks, &b0, &bn)) return rc;
+    if (npieces <= 0 || piece < 0 || piece >= npieces) return comm_fail("srcnn_tiled_piece: bad piece / npieces");
+    const unsigned a = b0 + (unsigned)((unsigned long long)bn * (unsigned)piece / (unsigned)npieces);
+    const unsigned b = b0 + (unsigned)((unsigned long long)bn * ((unsigned)piece + 1) / (unsigned)npieces);
+    if (row0) *row0 = a;
+    if (rows) *rows = b - a;
+    return SRCNN_OK;
+}
+
 int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_band, float* d_full, int root,
                                          int sub_bands, void* stream)
 {
@@ -275,27 +290,29 @@ int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned
         }
     }
     // piece i of rank r: rows [row0_r + rows_r*i/nsub, row0_r + rows_r*(i+1)/nsub) -- every rank computes the same table
-    std::vector<unsigned> row0((size_t)v.nranks), rows((size_t)v.nranks);
-    for (int r = 0; r < v.nranks; ++r) srcnn_band_rows(dh, r, v.nranks, &row0[r], &rows[r]);
-    auto cut = [&](int r, unsigned i) { return row0[r] + (unsigned)((unsigned long long)rows[r] * i / nsub); };
-    if (rows[v.rank] && !d_band) return comm_fail("srcnn_comm_tiled: d_band == NULL");
+    unsigned my_row0 = 0, my_rows = 0;
+    srcnn_band_rows(dh, v.rank, v.nranks, &my_row0, &my_rows);
+    if (my_rows && !d_band) return comm_fail("srcnn_comm_tiled: d_band == NULL");
     // the comm stream must not start before what is already queued on the caller's stream (e.g. the upload of d_in on the
     // root, or a previous frame's use of d_full)
     if (hipEventRecord(g_events[nsub], s) != hipSuccess || hipStreamWaitEvent(g_comm_stream, g_events[nsub], 0) != hipSuccess)
         return comm_fail("srcnn_comm_tiled: stream hand-over failed");
     std::vector<size_t> counts((size_t)v.nranks), offs((size_t)v.nranks);
     for (unsigned i = 0; i < nsub; ++i) {
-        const unsigned a = cut(v.rank, i), b = cut(v.rank, i + 1);
-        float* piece = d_band ? d_band + (size_t)(a - row0[v.rank]) * dw : nullptr;
-        if (b > a) {
-            int rc = srcnn_y_upscale2x_f32_band_dev(d_in, w, h, a, b - a, piece, stream);
+        unsigned a = 0, n = 0;
+        srcnn_tiled_piece(dh, v.rank, v.nranks, (int)i, (int)nsub, &a, &n);
+        float* piece = d_band ? d_band + (size_t)(a - my_row0) * dw : nullptr;
+        if (n) {
+            int rc = srcnn_y_upscale2x_f32_band_dev(d_in, w, h, a, n, piece, stream);
             if (rc) return rc;
         }
         if (hipEventRecord(g_events[i], s) != hipSuccess || hipStreamWaitEvent(g_comm_stream, g_events[i], 0) != hipSuccess)
             return comm_fail("srcnn_comm_tiled: event hand-over failed");
         for (int r = 0; r < v.nranks; ++r) {
-            counts[r] = (size_t)(cut(r, i + 1) - cut(r, i)) * dw;
-            offs[r] = (size_t)cut(r, i) * dw;
+            unsigned ra = 0, rn = 0;
+            srcnn_tiled_piece(dh, r, v.nranks, (int)i, (int)nsub, &ra, &rn);
+            counts[r] = (size_t)rn * dw;
+            offs[r] = (size_t)ra * dw;
         }
         int rc = srcnn_comm_gatherv_at_f32(piece, counts.data(), offs.data(), d_full, root, g_comm_stream);
         if (rc) return rc;

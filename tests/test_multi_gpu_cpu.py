@@ -146,3 +146,31 @@ def test_launcher_dry_run_script():
     lines = [json.loads(x) for x in r.stdout.strip().splitlines()]
     assert [x["world"] for x in lines] == [2, 8]
     assert lines[1]["band_rows"][7] == [7560, 1080] and lines[1]["band_MB"][0] == 66.4
+
+
+def test_c_band_and_piece_partition_matches_python_and_tiles_the_frame():
+    """The C side of the tiled frame (srcnn_band_rows / srcnn_tiled_piece, no device needed): bands == the Python partition
+    the gloo tests exercise; the pieces of every band tile it in order; all pieces of all ranks tile [0, out_h) exactly once
+    -- for ragged heights, more ranks than rows, and every sub-band count the library accepts."""
+    import ctypes as C
+    import libsrcnn_amd as S
+    L = S.lib()
+    for out_h in (1, 2, 7, 46, 90, 4320, 8640, 8641):
+        for world in (1, 2, 3, 8):
+            covered = np.zeros(out_h, np.int32)
+            for r in range(world):
+                r0, rn = C.c_uint(), C.c_uint()
+                assert L.srcnn_band_rows(out_h, r, world, C.byref(r0), C.byref(rn)) == 0
+                assert (r0.value, rn.value) == multigpu.band_rows(out_h, r, world)
+                for nsub in (1, 2, 4, 5, 16):
+                    pos = r0.value
+                    for i in range(nsub):
+                        a, n = C.c_uint(), C.c_uint()
+                        assert L.srcnn_tiled_piece(out_h, r, world, i, nsub, C.byref(a), C.byref(n)) == 0
+                        assert a.value == pos
+                        pos += n.value
+                        if nsub == 4:
+                            covered[a.value:a.value + n.value] += 1
+                    assert pos == r0.value + rn.value
+            assert (covered == 1).all()
+    assert L.srcnn_band_rows(10, 3, 3, None, None) != 0 and L.srcnn_tiled_piece(10, 0, 2, 4, 4, None, None) != 0
