@@ -247,6 +247,10 @@ int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, un
  * of ProcessSRCNN lanes created so far (at most 4 per context), both summed over the contexts. */
 int srcnn_debug_counts(int* tables, int* lanes);
 
+/* Test hook (no device needed): the band cut points srcnn_process_u8 uses for output rows [r0, r1) of a dw-wide image under
+ * the current workspace limit; returns their number (first = r0, last = r1), writes at most `cap` of them. */
+int srcnn_debug_band_plan(unsigned r0, unsigned r1, unsigned dw, int one_of_many, unsigned* cuts, int cap);
+
 /* ---- multi-GPU, one process per GPU: RCCL over xGMI only for the band gather.  The communicator binds to the calling
  * thread's current context (its device).
  * The unique id is produced on rank 0 and handed to the other ranks by the caller's own

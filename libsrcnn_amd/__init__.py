@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = [
     "srcnn_process_u8",
     "srcnn_delete_array", "srcnn_output_size", "srcnn_axis_table",
     "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_rank", "srcnn_comm_gather_f32",
-    "srcnn_comm_gatherv_f32", "srcnn_comm_gatherv_at_f32", "srcnn_comm_tiled_y_upscale2x_f32_dev", "srcnn_band_rows", "srcnn_tiled_piece",
+    "srcnn_comm_gatherv_f32", "srcnn_comm_gatherv_at_f32", "srcnn_comm_tiled_y_upscale2x_f32_dev", "srcnn_band_rows", "srcnn_tiled_piece", "srcnn_debug_band_plan",
     "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_debug_counts", "srcnn_fused_diag",
 ]
 CXX_SYMBOLS = ["_Z20ConfigureFilterSRCNN15SRCNNFilterTypeb", "_Z12ProcessSRCNNPKhjjjfRPhRjPS1_Pj"]
@@ -72,6 +72,7 @@ def lib():
             "srcnn_comm_tiled_y_upscale2x_f32_dev": (i, [vp, u, u, vp, vp, i, i, vp]),
             "srcnn_band_rows": (i, [u, i, i, C.POINTER(u), C.POINTER(u)]),
             "srcnn_tiled_piece": (i, [u, i, i, i, i, C.POINTER(u), C.POINTER(u)]),
+            "srcnn_debug_band_plan": (i, [u, u, u, i, C.POINTER(u), i]),
             "srcnn_shutdown": (None, []), "srcnn_last_error": (C.c_char_p, []), "srcnn_set_mode": (i, [i]),
             "srcnn_get_mode": (i, []), "srcnn_device_name": (i, [C.c_char_p, sz]),
             "srcnn_set_workspace_limit": (sz, [sz]),

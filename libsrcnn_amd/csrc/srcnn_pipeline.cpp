@@ -421,6 +421,16 @@ using namespace srcnn;
 
 extern "C" {
 
+// Test hook (no device needed): the band cut points srcnn_process_u8 would use for output rows [r0, r1) of a dw-wide image
+// under the current workspace limit.  Writes up to `cap` cut points (first = r0, last = r1), returns how many there are.
+int srcnn_debug_band_plan(unsigned r0, unsigned r1, unsigned dw, int one_of_many, unsigned* cuts, int cap)
+{
+    if (r1 <= r0 || dw == 0) return fail(SRCNN_E_ARG, "empty row range");
+    const std::vector<unsigned> c = band_starts(r0, r1, dw, one_of_many != 0);
+    for (int i = 0; i < (int)c.size() && i < cap; ++i) cuts[i] = c[i];
+    return (int)c.size();
+}
+
 // ---- host-pointer conveniences -----------------------------------------------------------------
 int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter, float* out)
 {

@@ -1,5 +1,6 @@
 """CPU: the C-ABI library loads, exports every symbol include/*.h declares, refuses to compute without
 a device, and its host-side table builder agrees with the oracle.  No GPU compute calls here."""
+import ctypes as C
 import os
 import re
 
@@ -139,3 +140,28 @@ int main() {
     assert out[2] in ("0", "-200")
     if out[2] == "0":
         assert out[3] == str(8 * 8 * 3)
+
+
+def test_process_band_plan_partitions_and_honours_the_workspace_limit(S):
+    """srcnn_process_u8's band cut points (host logic, no device): they partition the row range in order, interior cuts are
+    multiples of 16 rows, and no band holds more layer-2 scratch (128 B per output pixel) than srcnn_set_workspace_limit
+    allows -- except the documented 16-row floor."""
+    L = S.lib()
+    cuts = (C.c_uint * 4096)()
+    prev = L.srcnn_set_workspace_limit(16 << 30)
+    try:
+        for limit in (16 << 30, 1 << 30, 64 << 20, 1 << 20):
+            L.srcnn_set_workspace_limit(limit)
+            for (r0, r1, dw, many) in [(0, 4320, 7680, 0), (0, 540, 7680, 1), (1072, 2160, 3840, 1), (0, 300, 800, 0), (0, 8640, 15360, 0), (5, 6, 9, 0)]:
+                n = L.srcnn_debug_band_plan(r0, r1, dw, many, cuts, 4096)
+                assert 2 <= n <= 4096
+                c = list(cuts[:n])
+                assert c[0] == r0 and c[-1] == r1 and all(a < b for a, b in zip(c, c[1:]))
+                cap_rows = max(16, limit // (128 * dw) - 4)
+                for a, b in zip(c, c[1:]):
+                    assert b - a <= cap_rows, (limit, r0, r1, dw, a, b, cap_rows)
+                if r1 - r0 >= 512:
+                    assert n >= 4                      # large ranges are always pipelined over several bands
+    finally:
+        L.srcnn_set_workspace_limit(prev)
+    assert L.srcnn_debug_band_plan(10, 10, 100, 0, cuts, 16) < 0
