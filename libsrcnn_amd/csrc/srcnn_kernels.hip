@@ -263,7 +263,8 @@ constexpr int RS_TH = 16;                      // tile rows
 constexpr int RS_MAX_TPB = 16;                 // row tiles a block may march through (its horizontal weights are loaded once)
 constexpr int rs_lds_bytes(int np, int maxt, int sr, int lw)
 {
-    return RS_TH * maxt * 8 + RS_TH * 2 * 4 + np * (sr + 1 + RS_TH) * lw * 4;
+    // vertical weights / first rows / tap counts and the source patch are double-buffered; the intermediate rows are not
+    return 2 * (RS_TH * maxt * 8 + RS_TH * 2 * 4) + np * (2 * sr + RS_TH) * lw * 4;
 }
 
 // One tile row of the vertical pass with a compile-time tap count: source rows rb .. rb+CNT-1 of the patch are LW floats
@@ -298,12 +299,12 @@ __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
     constexpr int RPT = TH / 4;                // rows per thread in the horizontal pass
     constexpr int ZC = LW - 1;                 // the zero column every mid row ends with
     extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
-    double* vw = reinterpret_cast<double*>(rs_lds);            // [TH][MAXT]
-    int* vf = reinterpret_cast<int*>(vw + TH * MAXT);          // [TH] first source row, relative to the patch
-    int* vn = vf + TH;                                         // [TH] taps
-    float* raw = reinterpret_cast<float*>(vn + TH);            // [NP][sr][LW]
+    double* vw2 = reinterpret_cast<double*>(rs_lds);           // [2][TH][MAXT]
+    int* vf2 = reinterpret_cast<int*>(vw2 + 2 * TH * MAXT);    // [2][TH] first source row, relative to the patch
+    int* vn2 = vf2 + 2 * TH;                                   // [2][TH] taps
+    float* mid = reinterpret_cast<float*>(vn2 + 2 * TH);       // [NP][TH][LW]   (rows wv, wv+4, ... belong to wave wv alone)
+    float* raw2 = mid + NP * TH * LW;                          // [2][NP][sr][LW]
     const int raw_plane = a.sr * LW;
-    float* mid = raw + NP * raw_plane;                         // [NP][TH][LW]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0t = blockIdx.x * 256;
@@ -332,12 +333,21 @@ __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
     if (tid < NP * TH) mid[tid * LW + ZC] = 0.f;                 // the zero column (never overwritten: cn < LW)
 
     const int x = x0t + 4 * lane;
+    // Tile loop with ONE workgroup barrier per tile.  The patch and the vertical weights are double-buffered, and a wave
+    // consumes in the horizontal pass exactly the intermediate rows it produced in the vertical pass (rows wv, wv+4, ...), so
+    // the hand-over between the passes is wave-local.  A wave that runs ahead may already fetch tile s+1 into the other
+    // buffer while slower waves still read tile s; it cannot get two tiles ahead, because the barrier of tile s+1 waits for
+    // every wave to have left tile s.
     for (int sub = 0; sub < a.tpb; ++sub) {
         const int ry0 = (blockIdx.y * a.tpb + sub) * TH;
         if (ry0 >= a.dst_rows) break;
         const int rows = min(TH, a.dst_rows - ry0);
         const int y0 = a.dst_row0 + ry0, yl = y0 + rows - 1;
         const int vmin = a.vfirst[y0], nsrc = a.vfirst[yl] + a.vtaps[yl] - vmin;     // closed-form row span
+        double* vw = vw2 + (sub & 1) * TH * MAXT;
+        int* vf = vf2 + (sub & 1) * TH;
+        int* vn = vn2 + (sub & 1) * TH;
+        float* raw = raw2 + (sub & 1) * NP * raw_plane;
 
         // ---- everything this tile needs from global memory is requested now ----
         // (1) KIND 2: the Y' values this thread will merge with
@@ -405,7 +415,10 @@ __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
             default: break;
             }
         }
-        __syncthreads();
+        // this wave's intermediate rows are complete and visible to its own lanes: no workgroup barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- horizontal pass (same as k_resample_rows_reg), four columns per lane, then the sink ----
         if (x < a.dst_w) {
 #pragma unroll
@@ -473,7 +486,10 @@ __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
                 }
             }
         }
-        __syncthreads();                       // the next tile overwrites raw / mid / vw
+        // the wave's own next vertical pass overwrites its intermediate rows: its lanes must be done reading them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
