@@ -221,7 +221,10 @@ __global__ __launch_bounds__(R2_TW) void k_resample_2d(
 // at 4 waves per SIMD (110 VGPRs); the rest is exposed latency around the two barriers of a tile.  Prefetching the next
 // tile's patch into registers while the current tile computes was tried and is SLOWER (0.088 ms: the 9 extra values per
 // plane push the kernel to 168 VGPRs = 3 waves per SIMD; capped at 128 VGPRs it spills, 0.091 ms) -- occupancy hides the
-// latency better than software pipelining does here.
+// latency better than software pipelining does here.  Nor does more occupancy help: with TWO columns per lane (80 VGPRs,
+// 6 waves per SIMD) the kernel takes 0.079-0.088 ms.  The tap itself (v_cvt_f64_f32 + v_mul_f64 + v_add_f64) issues at
+// 4.9 cycles per instruction (profiles/r03_valu_rates.txt; v_fma_f64(w, x, 0) instead of v_mul_f64 is no faster), which
+// puts the pure-issue floor of the 8.6 taps per output sample at ~0.042 ms.
 // =============================================================================================
 struct Rs2dArgs {
     const float* src_plane; const unsigned char* src_rgb; int src_w;

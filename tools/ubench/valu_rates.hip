@@ -13,13 +13,14 @@
 typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int CH = 16;
 
-enum Mode { FMA32, MULADD32, PKFMA, PKMULADD, MUL_CVT_ADD64, ADD64, FMA64, CVT64, MULADD32_SGPR, PKMULADD_SGPR, NMODES };
+enum Mode { FMA32, MULADD32, PKFMA, PKMULADD, MUL_CVT_ADD64, ADD64, FMA64, CVT64, MULADD32_SGPR, PKMULADD_SGPR, MUL64, MULADD64, FMA0ADD64, NMODES };
 const char* kNames[NMODES] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_pk_fma_f32", "v_pk_mul_f32+v_pk_add_f32",
                               "v_mul_f32+v_cvt_f64_f32+v_add_f64", "v_add_f64", "v_fma_f64", "v_cvt_f64_f32+v_cvt_f32_f64",
-                              "v_mul_f32(sgpr)+v_add_f32", "v_pk_mul_f32(sgpr)+v_pk_add_f32"};
+                              "v_mul_f32(sgpr)+v_add_f32", "v_pk_mul_f32(sgpr)+v_pk_add_f32",
+                              "v_mul_f64", "v_cvt_f64_f32+v_mul_f64+v_add_f64 (resampler tap)", "v_cvt_f64_f32+v_fma_f64(w,x,0)+v_add_f64"};
 // VALU instructions per chain step, and useful "MAC-equivalents" (multiply-accumulates) per chain step
-const int kInstr[NMODES] = {1, 2, 1, 2, 3, 1, 1, 2, 2, 2};
-const int kMacs[NMODES]  = {1, 1, 2, 2, 1, 1, 1, 1, 1, 2};
+const int kInstr[NMODES] = {1, 2, 1, 2, 3, 1, 1, 2, 2, 2, 1, 3, 3};
+const int kMacs[NMODES]  = {1, 1, 2, 2, 1, 1, 1, 1, 1, 2, 1, 1, 1};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, float a, float b, int iters, const float* __restrict__ wt)
@@ -79,6 +80,30 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b, int iters
         for (int it = 0; it < iters; ++it)
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc[c] = __builtin_fma(acc[c], ad, bd);
+        double s = 0; for (int c = 0; c < CH; ++c) s += acc[c];
+        out[tid] = (float)s;
+    } else if constexpr (MODE == MUL64) {
+        double acc[CH]; const double ad = 1.0 + 1e-9 * a;
+        for (int c = 0; c < CH; ++c) acc[c] = tid * 1e-9 + c + 1;
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] = acc[c] * ad;
+        double s = 0; for (int c = 0; c < CH; ++c) s += acc[c];
+        out[tid] = (float)s;
+    } else if constexpr (MODE == MULADD64 || MODE == FMA0ADD64) {
+        // the resampler's tap: acc = acc + w * (double)x, product and sum rounded separately.  FMA0ADD64 writes the product
+        // as fma(w, x, +0.0): the same value (the +0.0 only matters for a -0 product, which the add swallows either way)
+        double acc[CH]; float v[CH]; const double wd = 0.25 + 1e-9 * a;
+        for (int c = 0; c < CH; ++c) { acc[c] = tid * 1e-9 + c; v[c] = tid * 1e-9f + c; }
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const double x = (double)v[c];
+                double p;
+                if constexpr (MODE == MULADD64) p = wd * x; else p = __builtin_fma(wd, x, 0.0);
+                acc[c] = acc[c] + p;
+                v[c] = v[c] + 1.0f;
+            }
         double s = 0; for (int c = 0; c < CH; ++c) s += acc[c];
         out[tid] = (float)s;
     } else if constexpr (MODE == CVT64) {
@@ -156,6 +181,9 @@ int main(int argc, char** argv)
         run<CVT64>(b, cus, ghz, d_out, d_w);
         run<MULADD32_SGPR>(b, cus, ghz, d_out, d_w);
         run<PKMULADD_SGPR>(b, cus, ghz, d_out, d_w);
+        run<MUL64>(b, cus, ghz, d_out, d_w);
+        run<MULADD64>(b, cus, ghz, d_out, d_w);
+        run<FMA0ADD64>(b, cus, ghz, d_out, d_w);
         printf("\n");
     }
     return 0;
