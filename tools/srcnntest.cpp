@@ -130,7 +130,7 @@ int main(int argc, char** argv)
 
     char dev[256] = "";
     int init_rc;
-    if (devices.empty()) init_rc = srcnn_init(0);
+    if (devices.empty()) init_rc = srcnn_init(-1);           // env SRCNN_DEVICES (all | id,id,...) or device 0
     else if (devices == "all") init_rc = srcnn_init_devices(nullptr, 0);
     else {
         std::vector<int> ids;
