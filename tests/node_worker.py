@@ -26,6 +26,12 @@ def image(h, w, d, seed):
     return img
 
 
+def devices(nctx):
+    """Context k -> HIP device k mod (visible devices): K virtual contexts on a one-GPU box, real peers on a multi-GPU node."""
+    nd = max(1, S.device_count())
+    return [k % nd for k in range(nctx)]
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -41,7 +47,7 @@ def cmd_process(nctx):
     depths), vs the single-context result (4K), and from 4 host threads at once."""
     res = {}
     orc = oracle.Oracle()
-    n = S.init_devices([0] * nctx)
+    n = S.init_devices(devices(nctx))
     res["contexts"] = n
     S.ConfigureFilterSRCNN(S.SRCNNF_Bicubic, False)
     cases = [(image(1100, 1200, 3, 11), 2.0, 2), (image(900, 1400, 4, 12), 1.5, 3), (image(1300, 1000, 3, 13), 3.0, 1),
@@ -100,7 +106,7 @@ def cmd_process(nctx):
 
 def cmd_node_tiled(nctx):
     """srcnn_y_upscale2x_f32_node_dev over `nctx` virtual contexts == the whole-frame call, bit for bit."""
-    res = {"contexts": S.init_devices([0] * nctx), "cases": []}
+    res = {"contexts": S.init_devices(devices(nctx)), "cases": []}
     L = S.lib()
     for (h, w, nsub, root) in [(1080, 1920, 4, 0), (333, 501, 3, 0), (333, 501, 1, 1), (97, 64, 5, nctx - 1), (40, 40, 16, 0)]:
         y = synth.plane(h, w, synth.SEED0 + h, "noise")
@@ -128,7 +134,7 @@ def cmd_node_tiled(nctx):
 
 def cmd_stream(nctx):
     """Host-frame stream dealt over the contexts == frame-by-frame results."""
-    res = {"contexts": S.init_devices([0] * nctx)}
+    res = {"contexts": S.init_devices(devices(nctx))}
     frames = synth.frames(5, 270, 480, 7, "smooth")
     singles = np.stack([S.y_upscale2x(f) for f in frames])
     for g in (False, True, True):
