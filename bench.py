@@ -377,6 +377,14 @@ def side_workload(args):
     cpu0 = None
     if args.workload == "tiled8k":
         import hashlib
+        if world > ndev:
+            # the band gather is a real RCCL exchange, and RCCL refuses two ranks on one device
+            if rank == 0:
+                print("bench.py: --workload tiled8k needs one GPU per rank (%d ranks, %d device(s) visible)" % (world, ndev), file=sys.stderr)
+            barrier()
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(4)
         w, h = args.tiled_size
         y = synth.plane(h, w, synth.SEED0, "smooth")          # every rank can generate the frame (counter-based)
         d_in = S.DeviceBuffer.from_numpy(y)
