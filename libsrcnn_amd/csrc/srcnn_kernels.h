@@ -105,6 +105,7 @@ void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, flo
 hipError_t conv12_mfma_prepare();
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                         int out_rows, bool strict, int num_cus, int variant, hipStream_t s);
+void conv12_grid_info(int num_cus, int variant, int* blocks, int* tile_rows);
 hipError_t conv12_f16_prepare();
 void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                        int out_rows, int num_cus, hipStream_t s);

@@ -1561,6 +1561,21 @@ static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, f
                            C2, plane_stride, out_row0, out_rows, tiles_x, ntiles);
 }
 
+// Resident workgroups of the production layer-1+2 kernel (it loops over 64 x TH tiles with a static stride) and its tile
+// height: what a band planner needs to cut bands whose tile count fills whole rounds of the grid.
+void conv12_grid_info(int num_cus, int variant, int* blocks, int* tile_rows)
+{
+    int bpc = 2, th = m_th(8);
+    switch (variant) {
+    case 0: bpc = 3; th = m_th(4); break;
+    case 2: bpc = 3; th = m_th(4); break;
+    case 3: bpc = 1; th = m_th(8); break;
+    default: break;
+    }
+    if (blocks) *blocks = bpc * num_cus;
+    if (tile_rows) *tile_rows = th;
+}
+
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                         int out_rows, bool strict, int num_cus, int variant, hipStream_t s)
 {

@@ -188,21 +188,48 @@ struct ProcJob {            // one srcnn_process_u8 call; shared (read-only) by 
     bool trace;
 };
 
-// Bands of a share [R0,R1): few and large at the front (every launch of the persistent layer kernels pays a ramp), small
-// at the end (the last band's D2H + fan-out cannot overlap anything).  Also no band larger than the workspace budget allows.
-std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, bool first_share_of_many)
+// Bands of a share [R0,R1) of a (dw x dh) output: about 30 / 30 / 25 / 10 / 5 % of the rows (a share of a multi-context call:
+// 45 / 35 / 15 / 5) -- large bands first, a short one last, because the last band's D2H + fan-out cannot overlap anything.
+// The exact cut points are chosen for the layer-1+2 kernel, which is persistent: `grid` resident workgroups walk a band's
+// 64 x tile_rows tiles with a static stride, so a band whose tile count is not a multiple of the grid wastes part of its
+// last round (a plain percentage split cost 68 rounds per 8K frame instead of 64: +6 % of the dominant kernel,
+// profiles/r03_process_summary.md).  Each cut is therefore moved, within +-30 % of its target height, to where the
+// layer-2 rows the band computes (its rows + 2 halo rows per interior side) fill their rounds best.  No band is larger than
+// the workspace budget allows.
+std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, unsigned dh, bool first_share_of_many, int grid, int tile_rows)
 {
     const unsigned rows = R1 - R0;
     const unsigned cap = budget_band_rows(dw);
     std::vector<unsigned> cuts{R0};
     if (rows >= 512) {
-        // 30 / 30 / 25 / 10 / 5 % (a share of a multi-context call: 45 / 35 / 15 / 5).  Banding itself costs nothing on the
-        // device (profiles/r03_band_probe.txt); the cut points only decide when the first D2H can start and how much is
-        // left to copy after the last kernel.
-        static const double five[] = {0.30, 0.60, 0.85, 0.95}, four[] = {0.45, 0.80, 0.95};
+        static const double five[] = {0.30, 0.30, 0.25, 0.10}, four[] = {0.45, 0.35, 0.15};
         const double* f = first_share_of_many ? four : five;
         const int nf = first_share_of_many ? 3 : 4;
-        for (int i = 0; i < nf; ++i) cuts.push_back(R0 + ((unsigned)(rows * f[i]) & ~15u));
+        const unsigned tiles_x = (dw + 63) / 64;
+        unsigned a = R0;
+        for (int i = 0; i < nf; ++i) {
+            const unsigned want = std::max(64u, (unsigned)(rows * f[i]));
+            unsigned b = a + (want & ~15u);
+            if (grid > 0 && tile_rows > 0) {
+                // layer-2 rows of band [a, b) = [max(a-2,0), min(b+2,dh)): choose their tile-row count T near the target
+                const unsigned top = a >= 2 ? 2 : a;
+                const unsigned t_want = (want + top + 2 + tile_rows - 1) / tile_rows;
+                const unsigned t_lo = std::max(1u, (unsigned)(t_want * 0.7)), t_hi = std::max(t_lo, (unsigned)(t_want * 1.3));
+                double best = -1.0;
+                unsigned best_t = t_want;
+                for (unsigned t = t_lo; t <= t_hi; ++t) {
+                    const unsigned long long tiles = (unsigned long long)t * tiles_x;
+                    const unsigned long long rounds = (tiles + grid - 1) / grid;
+                    const double fill = (double)tiles / (double)(rounds * grid);
+                    const double score = fill - 1e-4 * (t > t_want ? t - t_want : t_want - t);      // ties: closest to the target
+                    if (score > best) { best = score; best_t = t; }
+                }
+                b = a + best_t * tile_rows - top - 2;
+            }
+            if (b >= R1 || R1 - b < 32) break;
+            cuts.push_back(b);
+            a = b;
+        }
     }
     cuts.push_back(R1);
     // enforce the budget: split anything larger than `cap` rows
@@ -288,7 +315,9 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     }
 
     // ---- bands ----
-    const std::vector<unsigned> cuts = band_starts(R0, R1, dw, one_of_many);
+    int grid = 0, tile_rows = 0;
+    if (J.mode == SRCNN_MODE_STRICT && !G.conv12_valu) conv12_grid_info(cx.num_cus, G.conv12_variant, &grid, &tile_rows);
+    const std::vector<unsigned> cuts = band_starts(R0, R1, dw, dh, one_of_many, grid, tile_rows);
     const unsigned nb = (unsigned)cuts.size() - 1;
     unsigned max_band = 0;
     for (unsigned b = 0; b < nb; ++b) max_band = std::max(max_band, cuts[b + 1] - cuts[b]);
@@ -426,7 +455,9 @@ extern "C" {
 int srcnn_debug_band_plan(unsigned r0, unsigned r1, unsigned dw, int one_of_many, unsigned* cuts, int cap)
 {
     if (r1 <= r0 || dw == 0) return fail(SRCNN_E_ARG, "empty row range");
-    const std::vector<unsigned> c = band_starts(r0, r1, dw, one_of_many != 0);
+    int grid = 0, tile_rows = 0;
+    conv12_grid_info(256, G.conv12_variant, &grid, &tile_rows);          // an MI355X: 256 CUs
+    const std::vector<unsigned> c = band_starts(r0, r1, dw, r1, one_of_many != 0, grid, tile_rows);
     for (int i = 0; i < (int)c.size() && i < cap; ++i) cuts[i] = c[i];
     return (int)c.size();
 }
