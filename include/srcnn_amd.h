@@ -283,8 +283,10 @@ int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned
                                          int sub_bands, void* stream);
 /* rows [*row0, *row0 + *rows) of the out_h output rows that `rank` of `nranks` owns in the tiled path above */
 int srcnn_band_rows(unsigned out_h, int rank, int nranks, unsigned* row0, unsigned* rows);
-/* piece `piece` of `npieces` of that band (what one sub-band gather of the tiled path moves); needs no device */
-int srcnn_tiled_piece(unsigned out_h, int rank, int nranks, int piece, int npieces, unsigned* row0, unsigned* rows);
+/* piece `piece` of `npieces` of that band of an (out_w x out_h) frame (what one sub-band gather of the tiled path moves):
+ * large pieces first, a short one last, each cut where it fills whole rounds of the persistent layer-1+2 grid; a pure function
+ * of its arguments (no device needed), identical on every rank.  A short band yields fewer pieces: the rest have rows == 0. */
+int srcnn_tiled_piece(unsigned out_w, unsigned out_h, int rank, int nranks, int piece, int npieces, unsigned* row0, unsigned* rows);
 int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, void* stream);
 int srcnn_comm_barrier(void* stream);
 

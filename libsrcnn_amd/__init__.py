@@ -71,7 +71,7 @@ def lib():
             "srcnn_comm_gatherv_at_f32": (i, [vp, C.POINTER(sz), C.POINTER(sz), vp, i, vp]),
             "srcnn_comm_tiled_y_upscale2x_f32_dev": (i, [vp, u, u, vp, vp, i, i, vp]),
             "srcnn_band_rows": (i, [u, i, i, C.POINTER(u), C.POINTER(u)]),
-            "srcnn_tiled_piece": (i, [u, i, i, i, i, C.POINTER(u), C.POINTER(u)]),
+            "srcnn_tiled_piece": (i, [u, u, i, i, i, i, C.POINTER(u), C.POINTER(u)]),
             "srcnn_debug_band_plan": (i, [u, u, u, i, C.POINTER(u), i]),
             "srcnn_shutdown": (None, []), "srcnn_last_error": (C.c_char_p, []), "srcnn_set_mode": (i, [i]),
             "srcnn_get_mode": (i, []), "srcnn_device_name": (i, [C.c_char_p, sz]),

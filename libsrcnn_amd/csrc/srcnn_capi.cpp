@@ -663,6 +663,46 @@ unsigned budget_band_rows(unsigned dw)
     return (unsigned)std::min<size_t>(std::max<size_t>(16, fit > 4 ? fit - 4 : 1), 1u << 20);
 }
 
+// Cut output rows [R0,R1) of a (dw x dh) frame into pieces of about frac[0], frac[1], ... of the range (the last piece takes the
+// rest).  The layer-1+2 kernel is persistent: `grid` resident workgroups walk a piece's 64 x tile_rows tiles with a static
+// stride, so a piece whose tile count is not a multiple of the grid wastes part of its last round (a plain percentage split
+// of an 8K frame into 5 bands cost 68 rounds instead of 64, +6 % of the dominant kernel; four equal quarters of one rank's
+// band of a 16K frame 36 instead of 32).  Each cut is therefore moved, within +-30 % of its target height, to where the
+// layer-2 rows the piece computes (its rows + 2 halo rows per interior side) fill their rounds best.  Pure function of its
+// arguments: every rank of a tiled frame derives the same table.
+std::vector<unsigned> plan_cuts(unsigned R0, unsigned R1, unsigned dw, unsigned dh, const double* frac, int nfrac, int grid, int tile_rows)
+{
+    const unsigned rows = R1 - R0;
+    std::vector<unsigned> cuts{R0};
+    const unsigned tiles_x = (dw + 63) / 64;
+    unsigned a = R0;
+    for (int i = 0; i < nfrac; ++i) {
+        const unsigned want = std::max(32u, (unsigned)(rows * frac[i]));
+        unsigned b = a + (want & ~15u);
+        if (grid > 0 && tile_rows > 0) {
+            // layer-2 rows of piece [a, b) = [max(a-2,0), min(b+2,dh)): choose their tile-row count near the target
+            const unsigned top = a >= 2 ? 2 : a;
+            const unsigned t_want = (want + top + 2 + tile_rows - 1) / tile_rows;
+            const unsigned t_lo = std::max(1u, (unsigned)(t_want * 0.7)), t_hi = std::max(t_lo, (unsigned)(t_want * 1.3));
+            double best = -1.0;
+            unsigned best_t = t_want;
+            for (unsigned t = t_lo; t <= t_hi; ++t) {
+                const unsigned long long tiles = (unsigned long long)t * tiles_x;
+                const unsigned long long rounds = (tiles + grid - 1) / grid;
+                const double fill = (double)tiles / (double)(rounds * grid);
+                const double score = fill - 1e-4 * (t > t_want ? t - t_want : t_want - t);      // ties: closest to the target
+                if (score > best) { best = score; best_t = t; }
+            }
+            if (best_t * tile_rows > top + 2) b = a + best_t * tile_rows - top - 2;
+        }
+        if (b <= a || b >= R1 || R1 - b < 32) break;
+        cuts.push_back(b);
+        a = b;
+    }
+    cuts.push_back(R1);
+    return cuts;
+}
+
 // Output rows [r0,r1).  The 32 layer-2 planes are the big scratch (128 B per output pixel).  A range whose planes
 // would exceed the workspace budget (default 16 GiB, SRCNN_MAX_WORKSPACE_MB) is produced in horizontal bands --
 // bit-identical to the whole range -- so a 16K x 16K output needs the same scratch as an 8K one.

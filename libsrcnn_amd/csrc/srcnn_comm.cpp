@@ -121,6 +121,29 @@ int comm_fail(const char* what)
 
 }  // namespace
 
+namespace srcnn {
+std::vector<unsigned> tiled_cuts(unsigned out_w, unsigned out_h, int rank, int nranks, int npieces)
+{
+    unsigned b0 = 0, bn = 0;
+    srcnn_band_rows(out_h, rank, nranks, &b0, &bn);
+    if (bn == 0) return {b0, b0};
+    if (npieces <= 1 || bn < 256) {                               // short band: equal pieces, nothing to gain from planning
+        std::vector<unsigned> c((size_t)std::max(npieces, 1) + 1);
+        for (int i = 0; i <= std::max(npieces, 1); ++i) c[i] = b0 + (unsigned)((unsigned long long)bn * (unsigned)i / (unsigned)std::max(npieces, 1));
+        return c;
+    }
+    // decreasing targets n : n-1 : ... : 1 (40 / 30 / 20 / 10 % for 4 pieces): the piece whose gather stays exposed is the smallest.
+    // The grid is that of an MI355X (256 CUs), NOT a device query: the table must not depend on which rank computes it.
+    std::vector<double> frac((size_t)npieces - 1);
+    const double total = 0.5 * npieces * (npieces + 1);
+    for (int i = 0; i + 1 < npieces; ++i) frac[i] = (double)(npieces - i) / total;
+    int grid = 0, tile_rows = 0;
+    conv12_grid_info(256, G.conv12_variant, &grid, &tile_rows);
+    if (G.conv12_valu) grid = 0;
+    return plan_cuts(b0, b0 + bn, out_w, out_h, frac.data(), npieces - 1, grid, tile_rows);
+}
+}  // namespace srcnn
+
 extern "C" {
 
 int srcnn_comm_unique_id(unsigned char id[SRCNN_COMM_ID_BYTES])
@@ -253,16 +276,19 @@ int srcnn_band_rows(unsigned out_h, int rank, int nranks, unsigned* row0, unsign
     return SRCNN_OK;
 }
 
-// Piece `piece` of `npieces` of rank's band: rows [*row0, *row0 + *rows) of the out_h output rows.  The pieces of a band
-// partition it, the bands partition the frame; every rank derives the same table from (out_h, nranks, npieces) alone, which
-// is what keeps the per-piece gathers of srcnn_comm_tiled_y_upscale2x_f32_dev consistent without any exchange.
-int srcnn_tiled_piece(unsigned out_h, int rank, int nranks, int piece, int npieces, unsigned* row0, unsigned* rows)
+// Piece `piece` of `npieces` of rank's band of an (out_w x out_h) tiled frame: rows [*row0, *row0 + *rows).  The pieces of a
+// band partition it (large first, short last, cut where they fill whole rounds of the layer-1+2 grid: srcnn::tiled_cuts), the
+// bands partition the frame; every rank derives the same table from (out_w, out_h, nranks, npieces) alone, which is what keeps
+// the per-piece gathers of srcnn_comm_tiled_y_upscale2x_f32_dev consistent without any exchange.  A short band yields fewer
+// pieces; the missing ones are empty.
+int srcnn_tiled_piece(unsigned out_w, unsigned out_h, int rank, int nranks, int piece, int npieces, unsigned* row0, unsigned* rows)
 {
     unsigned b0 = 0, bn = 0;
     if (int rc = srcnn_band_rows(out_h, rank, nranks, &b0, &bn)) return rc;
-    if (npieces <= 0 || piece < 0 || piece >= npieces) return comm_fail("srcnn_tiled_piece: bad piece / npieces");
-    const unsigned a = b0 + (unsigned)((unsigned long long)bn * (unsigned)piece / (unsigned)npieces);
-    const unsigned b = b0 + (unsigned)((unsigned long long)bn * ((unsigned)piece + 1) / (unsigned)npieces);
+    if (npieces <= 0 || piece < 0 || piece >= npieces || out_w == 0) return comm_fail("srcnn_tiled_piece: bad piece / npieces / width");
+    const std::vector<unsigned> cuts = srcnn::tiled_cuts(out_w, out_h, rank, nranks, npieces);
+    const unsigned a = (size_t)piece < cuts.size() ? cuts[piece] : b0 + bn;
+    const unsigned b = (size_t)piece + 1 < cuts.size() ? cuts[piece + 1] : b0 + bn;
     if (row0) *row0 = a;
     if (rows) *rows = b - a;
     return SRCNN_OK;
@@ -300,7 +326,7 @@ int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned
     std::vector<size_t> counts((size_t)v.nranks), offs((size_t)v.nranks);
     for (unsigned i = 0; i < nsub; ++i) {
         unsigned a = 0, n = 0;
-        srcnn_tiled_piece(dh, v.rank, v.nranks, (int)i, (int)nsub, &a, &n);
+        srcnn_tiled_piece(dw, dh, v.rank, v.nranks, (int)i, (int)nsub, &a, &n);
         float* piece = d_band ? d_band + (size_t)(a - my_row0) * dw : nullptr;
         if (n) {
             int rc = srcnn_y_upscale2x_f32_band_dev(d_in, w, h, a, n, piece, stream);
@@ -310,7 +336,7 @@ int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned
             return comm_fail("srcnn_comm_tiled: event hand-over failed");
         for (int r = 0; r < v.nranks; ++r) {
             unsigned ra = 0, rn = 0;
-            srcnn_tiled_piece(dh, r, v.nranks, (int)i, (int)nsub, &ra, &rn);
+            srcnn_tiled_piece(dw, dh, r, v.nranks, (int)i, (int)nsub, &ra, &rn);
             counts[r] = (size_t)rn * dw;
             offs[r] = (size_t)ra * dw;
         }

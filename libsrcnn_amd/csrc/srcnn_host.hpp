@@ -237,6 +237,10 @@ int y_path_frame(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw
 int y_path_source_rows(Call& c, unsigned h, unsigned dh, int filter, unsigned r0, unsigned r1, unsigned& lo, unsigned& hi);
 // rows of layer-2 scratch one band may hold under the workspace budget (>= 16), for a dw-wide output
 unsigned budget_band_rows(unsigned dw);
+// cut [R0,R1) into pieces of about frac[i] of the range, each moved to where it fills whole rounds of the layer-1+2 grid
+std::vector<unsigned> plan_cuts(unsigned R0, unsigned R1, unsigned dw, unsigned dh, const double* frac, int nfrac, int grid, int tile_rows);
+// pieces of one rank's band of a tiled 2x frame (srcnn_tiled_piece): cut points, first = band start, last = band end
+std::vector<unsigned> tiled_cuts(unsigned out_w, unsigned out_h, int rank, int nranks, int npieces);
 
 // memcpy split over a few host threads: the destination is usually a fresh new[] block whose pages fault in on first
 // touch, which a single thread does at only a few GB/s.

@@ -189,49 +189,15 @@ struct ProcJob {            // one srcnn_process_u8 call; shared (read-only) by 
 };
 
 // Bands of a share [R0,R1) of a (dw x dh) output: about 30 / 30 / 25 / 10 / 5 % of the rows (a share of a multi-context call:
-// 45 / 35 / 15 / 5) -- large bands first, a short one last, because the last band's D2H + fan-out cannot overlap anything.
-// The exact cut points are chosen for the layer-1+2 kernel, which is persistent: `grid` resident workgroups walk a band's
-// 64 x tile_rows tiles with a static stride, so a band whose tile count is not a multiple of the grid wastes part of its
-// last round (a plain percentage split cost 68 rounds per 8K frame instead of 64: +6 % of the dominant kernel,
-// profiles/r03_process_summary.md).  Each cut is therefore moved, within +-30 % of its target height, to where the
-// layer-2 rows the band computes (its rows + 2 halo rows per interior side) fill their rounds best.  No band is larger than
-// the workspace budget allows.
+// 45 / 35 / 15 / 5) -- large bands first, a short one last, because the last band's D2H + fan-out cannot overlap anything --
+// with every cut moved to where the band fills whole rounds of the persistent layer-1+2 grid (plan_cuts).  No band is larger
+// than the workspace budget allows.
 std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, unsigned dh, bool first_share_of_many, int grid, int tile_rows)
 {
-    const unsigned rows = R1 - R0;
     const unsigned cap = budget_band_rows(dw);
-    std::vector<unsigned> cuts{R0};
-    if (rows >= 512) {
-        static const double five[] = {0.30, 0.30, 0.25, 0.10}, four[] = {0.45, 0.35, 0.15};
-        const double* f = first_share_of_many ? four : five;
-        const int nf = first_share_of_many ? 3 : 4;
-        const unsigned tiles_x = (dw + 63) / 64;
-        unsigned a = R0;
-        for (int i = 0; i < nf; ++i) {
-            const unsigned want = std::max(64u, (unsigned)(rows * f[i]));
-            unsigned b = a + (want & ~15u);
-            if (grid > 0 && tile_rows > 0) {
-                // layer-2 rows of band [a, b) = [max(a-2,0), min(b+2,dh)): choose their tile-row count T near the target
-                const unsigned top = a >= 2 ? 2 : a;
-                const unsigned t_want = (want + top + 2 + tile_rows - 1) / tile_rows;
-                const unsigned t_lo = std::max(1u, (unsigned)(t_want * 0.7)), t_hi = std::max(t_lo, (unsigned)(t_want * 1.3));
-                double best = -1.0;
-                unsigned best_t = t_want;
-                for (unsigned t = t_lo; t <= t_hi; ++t) {
-                    const unsigned long long tiles = (unsigned long long)t * tiles_x;
-                    const unsigned long long rounds = (tiles + grid - 1) / grid;
-                    const double fill = (double)tiles / (double)(rounds * grid);
-                    const double score = fill - 1e-4 * (t > t_want ? t - t_want : t_want - t);      // ties: closest to the target
-                    if (score > best) { best = score; best_t = t; }
-                }
-                b = a + best_t * tile_rows - top - 2;
-            }
-            if (b >= R1 || R1 - b < 32) break;
-            cuts.push_back(b);
-            a = b;
-        }
-    }
-    cuts.push_back(R1);
+    static const double five[] = {0.30, 0.30, 0.25, 0.10}, four[] = {0.45, 0.35, 0.15};
+    std::vector<unsigned> cuts = (R1 - R0 >= 512) ? plan_cuts(R0, R1, dw, dh, first_share_of_many ? four : five, first_share_of_many ? 3 : 4, grid, tile_rows)
+                                                  : std::vector<unsigned>{R0, R1};
     // enforce the budget: split anything larger than `cap` rows
     std::vector<unsigned> out{R0};
     for (size_t i = 1; i < cuts.size(); ++i) {
@@ -616,7 +582,9 @@ int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, fl
         NodeLane& N = cx.node;
         if (!N.st) HIP_TRY(hipStreamCreateWithFlags(&N.st, hipStreamNonBlocking));
         if (!N.copy_st) HIP_TRY(hipStreamCreateWithFlags(&N.copy_st, hipStreamNonBlocking));
-        const unsigned R0 = (unsigned)((unsigned long long)dh * k / nctx), R1 = (unsigned)((unsigned long long)dh * (k + 1) / nctx);
+        unsigned R0 = 0, Rn = 0;
+        (void)srcnn_band_rows(dh, (int)k, (int)nctx, &R0, &Rn);          // the same partition the tiled pieces are planned on
+        const unsigned R1 = R0 + Rn;
         if (R1 <= R0) return SRCNN_OK;
         std::vector<TableRef> tables;
         Call c;
@@ -640,8 +608,10 @@ int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, fl
         }
         // sub-bands: the kernels of sub-band i+1 are queued before the host waits for sub-band i and pushes it to the root
         // on the copy stream, so the push (one xGMI link per peer, all peers concurrently) hides behind compute
-        std::vector<unsigned> cut(nsub + 1);
-        for (unsigned i = 0; i <= nsub; ++i) cut[i] = R0 + (unsigned)((unsigned long long)(R1 - R0) * i / nsub);
+        // pieces: large first, short last, each cut where it fills whole rounds of the layer-1+2 grid (tiled_cuts); fewer than
+        // nsub pieces come back for a short band, the rest are empty
+        std::vector<unsigned> cut = tiled_cuts(dw, dh, (int)k, (int)nctx, (int)nsub);
+        while (cut.size() < nsub + 1) cut.push_back(R1);
         auto launch = [&](unsigned i) -> int {
             if (cut[i + 1] <= cut[i]) return SRCNN_OK;
             float* dst = is_root ? d_out + (size_t)cut[i] * dw : N.band + (size_t)(cut[i] - R0) * dw;

@@ -150,12 +150,13 @@ def test_launcher_dry_run_script():
 
 def test_c_band_and_piece_partition_matches_python_and_tiles_the_frame():
     """The C side of the tiled frame (srcnn_band_rows / srcnn_tiled_piece, no device needed): bands == the Python partition
-    the gloo tests exercise; the pieces of every band tile it in order; all pieces of all ranks tile [0, out_h) exactly once
-    -- for ragged heights, more ranks than rows, and every sub-band count the library accepts."""
+    the gloo tests exercise; the pieces of every band tile it in order (large first, whole rounds of the layer kernel's
+    grid); all pieces of all ranks tile [0, out_h) exactly once -- for ragged heights, more ranks than rows, and every
+    sub-band count the library accepts."""
     import ctypes as C
     import libsrcnn_amd as S
     L = S.lib()
-    for out_h in (1, 2, 7, 46, 90, 4320, 8640, 8641):
+    for out_h, out_w in ((1, 8), (2, 6), (7, 40), (46, 52), (90, 64), (4320, 7680), (8640, 15360), (8641, 15362)):
         for world in (1, 2, 3, 8):
             covered = np.zeros(out_h, np.int32)
             for r in range(world):
@@ -164,13 +165,34 @@ def test_c_band_and_piece_partition_matches_python_and_tiles_the_frame():
                 assert (r0.value, rn.value) == multigpu.band_rows(out_h, r, world)
                 for nsub in (1, 2, 4, 5, 16):
                     pos = r0.value
+                    sizes = []
                     for i in range(nsub):
                         a, n = C.c_uint(), C.c_uint()
-                        assert L.srcnn_tiled_piece(out_h, r, world, i, nsub, C.byref(a), C.byref(n)) == 0
+                        assert L.srcnn_tiled_piece(out_w, out_h, r, world, i, nsub, C.byref(a), C.byref(n)) == 0
                         assert a.value == pos
                         pos += n.value
+                        sizes.append(n.value)
                         if nsub == 4:
                             covered[a.value:a.value + n.value] += 1
                     assert pos == r0.value + rn.value
+                    if rn.value >= 1024 and nsub == 4:
+                        live = [s for s in sizes if s]
+                        assert live[-1] == min(live)                 # the piece whose gather stays exposed is the smallest
             assert (covered == 1).all()
-    assert L.srcnn_band_rows(10, 3, 3, None, None) != 0 and L.srcnn_tiled_piece(10, 0, 2, 4, 4, None, None) != 0
+    # 16K frame over 8 ranks, 4 pieces: the layer-1+2 kernel's rounds (512 resident workgroups, 64 x 16 tiles) stay within one of
+    # the unsplit band's, where four equal quarters cost 36 instead of 32
+    def rounds(a, b, out_w, out_h):
+        conv_rows = min(b + 2, out_h) - max(a - 2, 0)
+        return -(-(-(-conv_rows // 16) * ((out_w + 63) // 64)) // 512)
+    out_w, out_h = 15360, 8640
+    for r in range(8):
+        r0, rn = C.c_uint(), C.c_uint()
+        L.srcnn_band_rows(out_h, r, 8, C.byref(r0), C.byref(rn))
+        tot = 0
+        for i in range(4):
+            a, n = C.c_uint(), C.c_uint()
+            L.srcnn_tiled_piece(out_w, out_h, r, 8, i, 4, C.byref(a), C.byref(n))
+            if n.value:
+                tot += rounds(a.value, a.value + n.value, out_w, out_h)
+        assert tot <= rounds(r0.value, r0.value + rn.value, out_w, out_h) + 1, (r, tot)
+    assert L.srcnn_band_rows(10, 3, 3, None, None) != 0 and L.srcnn_tiled_piece(10, 10, 0, 2, 4, 4, None, None) != 0
