@@ -69,8 +69,8 @@ extern "C" {
  *
  * Threading contract.  Every entry point may be called from any host thread at any time.
  *   - srcnn_process_u8 / ProcessSRCNN are re-entrant like the reference's (src/libsrcnn.cpp:628-923 allocates
- *     everything per call): a call leases a private lane (streams, scratch, staging) for its duration; up to 4
- *     run concurrently, further callers wait for a lane.
+ *     everything per call): a call leases a private lane (streams, scratch, staging) for its duration; up to 4 per
+ *     context (env SRCNN_MAX_LANES) run concurrently, further callers wait for a lane.
  *   - *_dev calls take their scratch from the given stream's workspace; two threads using the SAME stream are
  *     serialised while they enqueue, different streams are independent.
  *   - The numerics mode is sampled once when a call starts; srcnn_set_mode never affects a call in flight.

@@ -56,6 +56,7 @@ Global::Global()
     shell_unfused = flag("SRCNN_SHELL_UNFUSED");
     const char* nu = getenv("SRCNN_NUMA");
     numa = !(nu && atoi(nu) == 0);
+    if (const char* ml = getenv("SRCNN_MAX_LANES")) max_lanes = (size_t)std::min(64, std::max(1, atoi(ml)));
 }
 
 // Never destroyed: at process exit the HIP runtime may already be gone when static destructors run, and the
@@ -431,7 +432,7 @@ LaneLease::LaneLease(Ctx& c) : cx(&c)
         for (auto& l : c.lanes)
             if (!l->busy) { lane = l.get(); break; }
         if (lane) break;
-        if (c.lanes.size() < kMaxLanes) {
+        if (c.lanes.size() < G.max_lanes) {
             auto l = std::make_unique<ProcLane>();
             if (hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&l->copy_st, hipStreamNonBlocking) != hipSuccess) {

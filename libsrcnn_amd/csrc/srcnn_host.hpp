@@ -127,7 +127,7 @@ struct ProcLane {
     void release_buffers();
     void release();
 };
-constexpr size_t kMaxLanes = 4;
+constexpr size_t kDefaultMaxLanes = 4;   // per context; env SRCNN_MAX_LANES (1..64) overrides
 constexpr size_t kMaxTables = 64;      // cache bound per context; only unreferenced tables are ever evicted
 
 // Per-context buffers of the node-level tiled frame (srcnn_y_upscale2x_f32_node_dev): the slab of the source frame this
@@ -179,6 +179,7 @@ struct Global {
     bool shell_unfused = false;       // SRCNN_SHELL_UNFUSED=1: colour shell as split + plane resamples + merge (A/B testing)
     bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
     bool numa = true;           // SRCNN_NUMA=0: do not place page-locked staging on the device's NUMA node
+    size_t max_lanes = kDefaultMaxLanes;   // concurrent ProcessSRCNN calls per context before callers queue
     Global();
 };
 extern Global& G;
