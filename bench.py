@@ -172,7 +172,7 @@ def process_srcnn_wall(S):
     return out
 
 
-def pcie_inclusive(S, frames=8):
+def pcie_inclusive(S, frames=16):
     """Stream of host-resident (page-locked) 4K Y frames: H2D + path + D2H per frame, two slots, hipGraph per slot."""
     step, free = host_stream_setup(S, frames)
     w, h, F = IN_W, IN_H, frames
@@ -411,7 +411,7 @@ def side_workload(args):
         label = "one %dx%d Y frame -> %dx%d, %d output bands (each in %d sub-bands, gather of sub-band k overlapped with " \
                 "the kernels of k+1) + RCCL gatherv to rank 0" % (w, h, 2 * w, 2 * h, world, tiled.nsub)
     elif args.workload == "host-stream":
-        F = max(args.frames, 8)
+        F = max(args.frames, 16)          # one call = one stream of F frames; the first H2D and the last D2H of a call are exposed
         step, cleanup = host_stream_setup(S, F)
         mpix_step = world * F * 4 * IN_W * IN_H / 1e6
         label = "stream of %d host-resident (page-locked) 3840x2160 Y frames per rank per step: H2D + path + D2H over two " \
