@@ -217,6 +217,34 @@ def cmd_process_paths(_):
     return {"process": ok, "y": ys}
 
 
+def cmd_queue(nctx):
+    """More concurrent ProcessSRCNN callers than lanes (the test sets SRCNN_MAX_LANES=1): callers queue for the lane, every
+    result is right, exactly one lane per context exists afterwards."""
+    S.init_devices(devices(max(1, nctx)))
+    orc = oracle.Oracle()
+    tc = [image(700, 1100, 3, 4), image(64, 80, 3, 1), image(720, 1000, 4, 2)]
+    want = [orc.process(im, 2.0) for im in tc]
+    errs = []
+
+    def worker(i):
+        try:
+            im = tc[i]
+            h, w, d = im.shape
+            for it in range(5):
+                rc, out, conv = S.ProcessSRCNN(im, w, h, d, 2.0)
+                if rc != 0 or not np.array_equal(out.reshape(want[i][0].shape), want[i][0]) or \
+                        not np.array_equal(conv.reshape(want[i][1].shape), want[i][1]):
+                    errs.append("thread %d it %d rc %d" % (i, it, rc))
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return {"errors": errs, "lanes": lanes(), "contexts": S.context_count()}
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
     arg = int(sys.argv[2]) if len(sys.argv) > 2 else 0

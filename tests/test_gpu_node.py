@@ -55,6 +55,12 @@ def test_rccl_tiled_call_with_overlapped_sub_band_gather():
     assert r["gatherv_at"]
 
 
+def test_more_callers_than_lanes_queue_up():
+    r = run("queue", 2, env={"SRCNN_MAX_LANES": "1"})
+    assert not r["errors"], r
+    assert r["contexts"] == 2 and r["lanes"] == 2, r            # one lane per context, shared by the three callers
+
+
 def test_env_srcnn_devices_self_init():
     r = run("env_devices", env={"SRCNN_DEVICES": "0,0,0"})
     assert r["contexts"] == 3 and r["equal"] and r["process_equal"] and r["lanes"] >= 3, r
