@@ -7,6 +7,7 @@
 // (src/frawscale.cpp:8-112 -> resample_table.hpp), grow-only per-stream device workspaces, and the
 // launch sequence that stands in for the body of libsrcnn::doSRCNN (src/libsrcnn.cpp:628-923).
 // There is deliberately no CPU compute path in this file: if HIP is unusable the calls fail.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -39,6 +40,41 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("SRCNN_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        void* h = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr;
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+}  // namespace
+
+TraceRange::TraceRange(const char* fmt, ...) : on_(roctx().push != nullptr)
+{
+    if (!on_) return;
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    (void)roctx().push(buf);
+}
+
+TraceRange::~TraceRange() { if (on_) (void)roctx().pop(); }
 
 Global::Global()
 {
@@ -621,6 +657,7 @@ int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw
         return SRCNN_OK;
     }
     if ((rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
+    TraceRange tr("srcnn y_path rows [%u,%u) of %ux%u", r0, r1, dw, dh);
     {
         StageTimer t(SRCNN_STAGE_RESAMPLE, c);
         if ((rc = resample_src_rows(c, src, w, h, dw, dh, filter, ua, ub, ws.up))) return rc;

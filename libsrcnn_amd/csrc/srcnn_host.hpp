@@ -184,6 +184,19 @@ struct Global {
 };
 extern Global& G;
 
+// ---- tracing: named ranges for rocprofv3 --marker-trace (the reference only has a wall-clock ms counter) ----
+// Off unless SRCNN_ROCTX=1: then librocprofiler-sdk-roctx is dlopen'ed once and every ProcessSRCNN call, band and stage of the
+// path pushes / pops a range, so a marker trace shows the host-side pipeline next to the kernels.
+class TraceRange {
+public:
+    explicit TraceRange(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+private:
+    bool on_;
+};
+
 // ---- contexts ----
 int ensure_init();                       // at least context 0 exists (lazy: device 0, or env SRCNN_DEVICES)
 Ctx* cur_ctx();                          // the calling thread's current context, device bound; nullptr + error if init fails

@@ -215,6 +215,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 {
     int rc = bind(cx);
     if (rc) return rc;
+    TraceRange tr("srcnn_process_u8 ctx %d rows [%u,%u) of %ux%ux%u -> %ux%u", cx.index, R0, R1, J.w, J.h, J.d, J.dw, J.dh);
     LaneLease lease(cx);
     if (lease.rc) return lease.rc;
     ProcLane& L = *lease.lane;
@@ -363,36 +364,46 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         return true;
     };
     auto fan_band = [&](unsigned b) {
+        TraceRange tf("srcnn fan-out band %u", b);
         if (hipEventSynchronize(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
         const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
         const size_t g0 = (size_t)cuts[b] * dw;
         parallel_memcpy(J.out + g0 * d, pin_rgb + p0 * d, pn * d);
         if (J.conv) parallel_memcpy(J.conv + g0, pin_conv + p0, pn);
     };
-    std::thread fanout;
-    const bool threaded = try_thread(fanout, [&] {
+    // Two helpers, so that neither kind of waiting delays the other: the COPIER waits for a band's kernels and queues its D2H
+    // on the idle copy stream at once; the FANNER waits for a landed band and copies it out to the caller's buffers.  (One
+    // helper doing both fanned band b-1 out only after band b's kernels had finished -- a marker trace showed the first
+    // fan-out starting 8 ms into a 13.9 ms call and the last two sitting in the tail.)  Both block; neither spins.
+    Handoff landed_q;                       // bands whose D2H has been queued (their "landed" event recorded)
+    std::thread copier, fanner;
+    const bool threaded = try_thread(copier, [&] {
         (void)hipSetDevice(cx.device);
-        // resolve the copy dependencies on the host: wait for a band's kernels, queue its D2H on the idle copy stream, and
-        // fan the previous band out to the caller's buffers while that copy is in flight
-        unsigned done = 0;
-        bool any = false;
         for (unsigned b = 0; b < nb; ++b) {
-            if (!enqueued.wait_for(b)) break;
-            if (!d2h_band(b)) return;
-            if (b > 0) fan_band(b - 1);
-            done = b; any = true;
+            if (!enqueued.wait_for(b) || !d2h_band(b)) { landed_q.cancel(); return; }
+            landed_q.publish(b + 1);
         }
-        if (any) fan_band(done);
+    });
+    const bool fan_threaded = threaded && try_thread(fanner, [&] {
+        (void)hipSetDevice(cx.device);
+        for (unsigned b = 0; b < nb; ++b) {
+            if (!landed_q.wait_for(b)) return;
+            fan_band(b);
+        }
     });
     int launch_rc = SRCNN_OK;
     for (unsigned b = 0; b < nb; ++b) {
+        TraceRange tb("srcnn band %u [%u,%u)", b, cuts[b], cuts[b + 1]);
         launch_rc = run_band(cuts[b], cuts[b + 1]);
         if (!launch_rc && hipEventRecord(L.band_events[2 * b], s) != hipSuccess) launch_rc = fail(SRCNN_E_HIP, "band %u event record failed", b);
         if (launch_rc) { enqueued.cancel(); break; }
         if (threaded) enqueued.publish(b + 1);
         else if (d2h_band(b)) fan_band(b);
     }
-    if (threaded) fanout.join();
+    if (threaded) copier.join();
+    if (fan_threaded) fanner.join();
+    else if (threaded && !launch_rc && !copy_err)
+        for (unsigned b = 0; b < nb; ++b) fan_band(b);            // the second helper could not be started: fan out here
     const auto t2 = now();
     // everything this call queued has completed by now (the helper waited for the last D2H event); these return at once
     hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(L.copy_st);
