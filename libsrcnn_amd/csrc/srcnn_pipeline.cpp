@@ -50,6 +50,23 @@ void hint_huge_pages(void* p, size_t n)
     if (e > a + (4u << 20)) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);
 }
 
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+// Fault the pages of a result buffer in BEFORE the fan-out needs them: the first few milliseconds of a large call belong to
+// the GPU alone, so a helper thread spends them on the page faults (and the zeroing the kernel does per fresh page) that the
+// fan-out memcpy would otherwise pay band by band, the last ones in the call's tail.  MADV_POPULATE_WRITE (Linux 5.14) does
+// not touch the data, so it is safe beside a memcpy that already writes the same range; where it is not available nothing
+// is done (the memcpy faults the pages itself, as before).
+void prefault_pages(void* p, size_t n)
+{
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
+    const size_t chunk = 8u << 20;
+    for (uintptr_t q = a; q < e; q += chunk)
+        if (madvise(reinterpret_cast<void*>(q), std::min<size_t>(chunk, e - q), MADV_POPULATE_WRITE) != 0) return;
+}
+
 constexpr unsigned kBlockingEvent = hipEventDisableTiming | hipEventBlockingSync;   // host waits sleep, they do not spin
 
 // Start a helper thread; false (and nothing started) if the system refuses -- callers then run the work inline.
@@ -300,21 +317,54 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 
     const size_t out_bytes = share_px * d;
     const bool small = out_bytes < (8u << 20) && !one_of_many;
-    // ---- stage-in: the share's source rows.  Small images go straight from the caller's (pageable) buffer. ----
+    // ---- stage-in.  Small images: the share's source rows in one go, straight from the caller's (pageable) buffer.  Large
+    //      images: band by band -- stage_rows(upto) brings source rows [staged, upto) through the page-locked staging to the
+    //      device (and, on the plane path, splits them), so the first band's kernels start after a third of the copy and the
+    //      rest of it hides behind them. ----
     const size_t src_off = (size_t)lo * w * d, src_bytes = (size_t)(hi - lo) * w * d;
-    if (small) {
-        HIP_TRY(hipMemcpyAsync(d_rgb + src_off, J.rgb + src_off, src_bytes, hipMemcpyHostToDevice, s));
-    } else {
+    unsigned staged = lo;                                      // source rows [lo, staged) are on the device
+    auto stage_rows = [&](unsigned upto) -> int {
+        upto = std::min(std::max(upto, staged), hi);
+        if (upto == staged) return SRCNN_OK;
+        const size_t off = (size_t)staged * w * d, nbytes = (size_t)(upto - staged) * w * d;
+        if (small) {
+            HIP_TRY(hipMemcpyAsync(d_rgb + off, J.rgb + off, nbytes, hipMemcpyHostToDevice, s));
+        } else {
+            parallel_memcpy(L.pin_in + (off - src_off), J.rgb + off, nbytes);
+            HIP_TRY(hipMemcpyAsync(d_rgb + off, L.pin_in + (off - src_off), nbytes, hipMemcpyHostToDevice, s));
+        }
+        if (!fused_shell)
+            launch_rgb_split(d_rgb + off, (size_t)(upto - staged) * w, (int)d, sp[0] + (size_t)staged * w, sp[1] + (size_t)staged * w,
+                             sp[2] + (size_t)staged * w, sp[3] + (size_t)staged * w, s);
+        staged = upto;
+        return SRCNN_OK;
+    };
+    auto band_source_end = [&](unsigned a, unsigned b, unsigned& upto) -> int {      // last source row (exclusive) band [a,b) reads
+        upto = hi;
+        if (identity) return SRCNN_OK;
+        unsigned l2 = 0, h2 = hi;
+        int r = y_path_source_rows(c, h, dh, J.filter, a, b, l2, h2);
+        if (r) return r;
+        if (cv) { unsigned cl, chh; cv->source_span(a, b, cl, chh); h2 = std::max(h2, std::min(chh, h)); }
+        else h2 = std::max(h2, std::min(b, h));
+        upto = std::min(h2, hi);
+        return SRCNN_OK;
+    };
+    std::thread prefault;
+    bool prefaulting = false;
+    if (!small) {
         if ((rc = grow_pinned(cx, L.pin_in, L.pin_in_n, src_bytes))) return rc;
         if ((rc = grow_pinned(cx, L.pin_out, L.pin_out_n, out_bytes + share_px))) return rc;
-        hint_huge_pages(J.out + (size_t)R0 * dw * d, out_bytes);
-        if (J.conv) hint_huge_pages(J.conv + (size_t)R0 * dw, share_px);
-        parallel_memcpy(L.pin_in, J.rgb + src_off, src_bytes);
-        HIP_TRY(hipMemcpyAsync(d_rgb + src_off, L.pin_in, src_bytes, hipMemcpyHostToDevice, s));
+        unsigned char* o0 = J.out + (size_t)R0 * dw * d;
+        unsigned char* c0 = J.conv ? J.conv + (size_t)R0 * dw : nullptr;
+        hint_huge_pages(o0, out_bytes);
+        if (c0) hint_huge_pages(c0, share_px);
+        prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes); if (c0) prefault_pages(c0, share_px); });
     }
-    if (!fused_shell)
-        launch_rgb_split(d_rgb + src_off, (size_t)(hi - lo) * w, (int)d, sp[0] + (size_t)lo * w, sp[1] + (size_t)lo * w,
-                         sp[2] + (size_t)lo * w, sp[3] + (size_t)lo * w, s);
+    struct JoinPrefault {                                      // whatever path leaves this function: the helper is joined first
+        std::thread& t; bool& on;
+        ~JoinPrefault() { if (on) t.join(); }
+    } join_prefault{prefault, prefaulting};
     const auto t1 = now();
 
     const YSource ysrc = fused_shell ? YSource::from_rgb(d_rgb, (int)d) : YSource::from_plane(sp[0]);
@@ -339,6 +389,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 
     if (small) {
         // small image: one shot on the lane's stream
+        if ((rc = stage_rows(hi))) return rc;
         if ((rc = run_band(R0, R1))) return rc;
         HIP_TRY(hipMemcpyAsync(J.out + (size_t)R0 * dw * d, d_out, out_bytes, hipMemcpyDeviceToHost, s));
         if (J.conv) HIP_TRY(hipMemcpyAsync(J.conv + (size_t)R0 * dw, d_conv, share_px, hipMemcpyDeviceToHost, s));
@@ -394,7 +445,10 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     int launch_rc = SRCNN_OK;
     for (unsigned b = 0; b < nb; ++b) {
         TraceRange tb("srcnn band %u [%u,%u)", b, cuts[b], cuts[b + 1]);
-        launch_rc = run_band(cuts[b], cuts[b + 1]);
+        unsigned upto = hi;
+        launch_rc = band_source_end(cuts[b], cuts[b + 1], upto);
+        if (!launch_rc) launch_rc = stage_rows(b + 1 == nb ? hi : upto);
+        if (!launch_rc) launch_rc = run_band(cuts[b], cuts[b + 1]);
         if (!launch_rc && hipEventRecord(L.band_events[2 * b], s) != hipSuccess) launch_rc = fail(SRCNN_E_HIP, "band %u event record failed", b);
         if (launch_rc) { enqueued.cancel(); break; }
         if (threaded) enqueued.publish(b + 1);
