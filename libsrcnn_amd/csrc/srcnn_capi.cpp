@@ -446,7 +446,8 @@ void ProcLane::release()
     band_events.clear();
     if (st) (void)hipStreamDestroy(st);
     if (copy_st) (void)hipStreamDestroy(copy_st);
-    st = copy_st = nullptr;
+    if (in_st) (void)hipStreamDestroy(in_st);
+    st = copy_st = in_st = nullptr;
 }
 
 void NodeLane::release()
@@ -471,7 +472,8 @@ LaneLease::LaneLease(Ctx& c) : cx(&c)
         if (c.lanes.size() < G.max_lanes) {
             auto l = std::make_unique<ProcLane>();
             if (hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&l->copy_st, hipStreamNonBlocking) != hipSuccess) {
+                hipStreamCreateWithFlags(&l->copy_st, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&l->in_st, hipStreamNonBlocking) != hipSuccess) {
                 l->release();
                 rc = fail(SRCNN_E_HIP, "could not create the streams of a ProcessSRCNN lane");
                 return;
@@ -492,6 +494,7 @@ LaneLease::~LaneLease()
     (void)hipSetDevice(cx->device);
     (void)hipStreamSynchronize(lane->st);
     (void)hipStreamSynchronize(lane->copy_st);
+    (void)hipStreamSynchronize(lane->in_st);
     { std::lock_guard<std::mutex> lk(cx->lane_mu); lane->busy = false; }
     cx->lane_cv.notify_one();
 }

@@ -119,11 +119,11 @@ struct StreamSlot {         // one lane of the host-stream path; lives until src
 // context; further callers wait for one.
 struct ProcLane {
     bool busy = false;
-    hipStream_t st = nullptr, copy_st = nullptr;
+    hipStream_t st = nullptr, copy_st = nullptr, in_st = nullptr;   // kernels / results out (D2H) / source rows in (H2D)
     Workspace ws;
     unsigned char* pin_in = nullptr;  size_t pin_in_n = 0;
     unsigned char* pin_out = nullptr; size_t pin_out_n = 0;
-    std::vector<hipEvent_t> band_events;
+    std::vector<hipEvent_t> band_events;      // per band: kernels done, result landed, source rows in
     void release_buffers();
     void release();
 };

@@ -309,7 +309,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     if (!no_planes && (rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
     if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * std::min(dh, max_band + 12)))) return rc;
     if (!fused_shell && (rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
-    while (L.band_events.size() < 2 * nb + 1) {
+    while (L.band_events.size() < 3 * nb + 1) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, kBlockingEvent));
         L.band_events.push_back(e);
@@ -323,6 +323,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     //      rest of it hides behind them. ----
     const size_t src_off = (size_t)lo * w * d, src_bytes = (size_t)(hi - lo) * w * d;
     unsigned staged = lo;                                      // source rows [lo, staged) are on the device
+    unsigned n_staged = 0;                                     // slabs staged so far (one "rows in" event each, at most one per band)
     auto stage_rows = [&](unsigned upto) -> int {
         upto = std::min(std::max(upto, staged), hi);
         if (upto == staged) return SRCNN_OK;
@@ -330,8 +331,14 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if (small) {
             HIP_TRY(hipMemcpyAsync(d_rgb + off, J.rgb + off, nbytes, hipMemcpyHostToDevice, s));
         } else {
+            // on the lane's own input stream, so that the copy runs BESIDE the previous band's kernels; the kernel stream
+            // waits for it device-side (a kernel queue waiting for a copy's event is fine -- it is a copy waiting behind a
+            // kernel queue that does not overlap on this runtime)
             parallel_memcpy(L.pin_in + (off - src_off), J.rgb + off, nbytes);
-            HIP_TRY(hipMemcpyAsync(d_rgb + off, L.pin_in + (off - src_off), nbytes, hipMemcpyHostToDevice, s));
+            hipEvent_t ev = L.band_events[2 * nb + n_staged++];
+            HIP_TRY(hipMemcpyAsync(d_rgb + off, L.pin_in + (off - src_off), nbytes, hipMemcpyHostToDevice, L.in_st));
+            HIP_TRY(hipEventRecord(ev, L.in_st));
+            HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         }
         if (!fused_shell)
             launch_rgb_split(d_rgb + off, (size_t)(upto - staged) * w, (int)d, sp[0] + (size_t)staged * w, sp[1] + (size_t)staged * w,
