@@ -205,15 +205,18 @@ struct ProcJob {            // one srcnn_process_u8 call; shared (read-only) by 
     bool trace;
 };
 
-// Bands of a share [R0,R1) of a (dw x dh) output: about 30 / 30 / 25 / 10 / 5 % of the rows (a share of a multi-context call:
-// 45 / 35 / 15 / 5) -- large bands first, a short one last, because the last band's D2H + fan-out cannot overlap anything --
+// Bands of a share [R0,R1) of a (dw x dh) output: about 10 / 30 / 30 / 20 / 7 / 3 % of the rows (a share of a multi-context call:
+// 45 / 35 / 15 / 5) -- a short band first so that the GPU starts early, a very short one last because its D2H + fan-out cannot
+// overlap anything --
 // with every cut moved to where the band fills whole rounds of the persistent layer-1+2 grid (plan_cuts).  No band is larger
 // than the workspace budget allows.
 std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, unsigned dh, bool first_share_of_many, int grid, int tile_rows)
 {
     const unsigned cap = budget_band_rows(dw);
-    static const double five[] = {0.30, 0.30, 0.25, 0.10}, four[] = {0.45, 0.35, 0.15};
-    std::vector<unsigned> cuts = (R1 - R0 >= 512) ? plan_cuts(R0, R1, dw, dh, first_share_of_many ? four : five, first_share_of_many ? 3 : 4, grid, tile_rows)
+    // a short first band (the GPU starts after a tenth of the input has been staged) and a very short last one (what is left
+    // to copy and fan out after the last kernel)
+    static const double six[] = {0.10, 0.30, 0.30, 0.20, 0.07}, four[] = {0.45, 0.35, 0.15};
+    std::vector<unsigned> cuts = (R1 - R0 >= 512) ? plan_cuts(R0, R1, dw, dh, first_share_of_many ? four : six, first_share_of_many ? 3 : 5, grid, tile_rows)
                                                   : std::vector<unsigned>{R0, R1};
     // enforce the budget: split anything larger than `cap` rows
     std::vector<unsigned> out{R0};
