@@ -369,7 +369,8 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         unsigned char* c0 = J.conv ? J.conv + (size_t)R0 * dw : nullptr;
         hint_huge_pages(o0, out_bytes);
         if (c0) hint_huge_pages(c0, share_px);
-        prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes); if (c0) prefault_pages(c0, share_px); });
+        static const bool no_prefault = [] { const char* e = getenv("SRCNN_PREFAULT"); return e && atoi(e) == 0; }();
+        if (!no_prefault) prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes); if (c0) prefault_pages(c0, share_px); });
     }
     struct JoinPrefault {                                      // whatever path leaves this function: the helper is joined first
         std::thread& t; bool& on;
