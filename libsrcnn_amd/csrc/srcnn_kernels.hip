@@ -224,7 +224,8 @@ __global__ __launch_bounds__(R2_TW) void k_resample_2d(
 // latency better than software pipelining does here.  Nor does more occupancy help: with TWO columns per lane (80 VGPRs,
 // 6 waves per SIMD) the kernel takes 0.079-0.088 ms.  The tap itself (v_cvt_f64_f32 + v_mul_f64 + v_add_f64) issues at
 // 4.9 cycles per instruction (profiles/r03_valu_rates.txt; v_fma_f64(w, x, 0) instead of v_mul_f64 is no faster), which
-// puts the pure-issue floor of the 8.6 taps per output sample at ~0.042 ms.
+// puts the pure-issue floor of the 8.6 taps per output sample at ~0.042 ms.  A 244-column tile (source span 127: two full
+// 64-lane sweeps of the vertical pass instead of two and a 6-lane third) does not help either: 0.076 ms.
 // =============================================================================================
 struct Rs2dArgs {
     const float* src_plane; const unsigned char* src_rgb; int src_w;
