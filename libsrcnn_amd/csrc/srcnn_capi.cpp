@@ -217,9 +217,14 @@ int make_context_locked(int device)
     auto fw = std::make_unique<FusedF16Weights>();
     build_fused_f16_weights(*dw, *fw);
     HIP_TRY(hipMalloc((void**)&cx->fused_w, sizeof(FusedF16Weights)));
+    struct FreeOnError {                       // the context is not published yet: a failure below must not leak its device block
+        Ctx* cx;
+        ~FreeOnError() { if (cx) { (void)hipFree(cx->fused_w); cx->fused_w = nullptr; } }
+    } guard{cx.get()};
     HIP_TRY(hipMemcpy(cx->fused_w, fw.get(), sizeof(FusedF16Weights), hipMemcpyHostToDevice));
     HIP_TRY(fused_f16_prepare());
     HIP_TRY(rs2d_prepare());
+    guard.cx = nullptr;
     cx->num_cus = prop.multiProcessorCount;
     cx->numa_node = device_numa_node(device);
     // direct copies between the devices of a node (the node-level tiled frame moves its bands with hipMemcpyPeerAsync)
