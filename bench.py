@@ -285,6 +285,18 @@ def reduce_min(dist, x):
     return -reduce_max(dist, -x)
 
 
+_RCCL_WEDGED = False       # a probe thread is stuck inside RCCL: leave with os._exit once the line is out (see leave())
+
+
+def leave():
+    """Normal return, unless a helper thread is wedged inside RCCL: then interpreter shutdown (atexit handlers, library
+    destructors) could wait for it for ever, so the process ends here, after flushing what it printed."""
+    if _RCCL_WEDGED:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+
+
 def rccl_probe(S, dist, rank, world, ndev, timeout_s=120.0):
     """Outside the timed region: create the RCCL communicator inside libsrcnn_amd.so across all ranks and run ONE
     srcnn_comm_barrier, so the line can say how many ranks RCCL actually connected (`rccl_ranks`).  The id travels
@@ -325,6 +337,8 @@ def rccl_probe(S, dist, rank, world, ndev, timeout_s=120.0):
     mine = float(res.get("n", 0))
     agreed = reduce_min(dist, mine)                              # every rank must have seen the same communicator
     if th.is_alive():
+        global _RCCL_WEDGED
+        _RCCL_WEDGED = True
         return None, "RCCL init/barrier did not finish within %.0f s on rank %d" % (timeout_s, rank)
     if agreed != world:
         return None, res.get("err", "RCCL connected %d of %d ranks" % (int(agreed), world))
@@ -480,6 +494,7 @@ def side_workload(args):
         L.srcnn_comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
+    leave()
 
 
 def dry_run_line(args, rank, world, dist):
@@ -720,9 +735,7 @@ def main():
         L.srcnn_comm_destroy()
     if dist is not None:
         dist.destroy_process_group()
-    if world > 1 and rccl_ranks is None and rccl_note and "did not finish" in rccl_note:
-        sys.stdout.flush()
-        os._exit(0)                        # a helper thread is wedged inside RCCL: do not let interpreter shutdown wait for it
+    leave()
 
 
 if __name__ == "__main__":
