@@ -462,11 +462,6 @@ def side_workload(args):
         label = "batch of 64 resident 1920x1080 frames per rank per step"
 
     comm_made = args.workload == "tiled8k"
-    if args.workload != "tiled8k" and world > 1:
-        extra["rccl_ranks"], note = rccl_probe(S, dist, rank, world, ndev)
-        comm_made = extra["rccl_ranks"] is not None
-        if note:
-            extra["rccl_note"] = note
 
     for _ in range(args.warmup):
         step()
@@ -482,6 +477,11 @@ def side_workload(args):
     cpu_s = reduce_max(dist, cpu_s)
     if verify is not None:
         extra["verify"] = verify()
+    if args.workload != "tiled8k" and world > 1:      # after the measurement, like the headline workload
+        extra["rccl_ranks"], note = rccl_probe(S, dist, rank, world, ndev)
+        comm_made = extra["rccl_ranks"] is not None
+        if note:
+            extra["rccl_note"] = note
     if rank == 0:
         print(json.dumps({"metric": METRIC + (" incl. PCIe" if args.workload == "host-stream" else ""),
                           "value": round(mpix_step / (ms * 1e-3), 2),
@@ -614,12 +614,6 @@ def main():
         S.sync()
         return (time.perf_counter() - t0) / k
 
-    # N > 1: prove, outside the timed region, that RCCL connects all N ranks (one communicator + one barrier); the
-    # headline data path itself has no collective
-    rccl_ranks, rccl_note = (None, None)
-    if world > 1:
-        rccl_ranks, rccl_note = rccl_probe(S, dist, rank, world, ndev)
-
     for _ in range(args.warmup):
         step()
     S.sync()
@@ -638,6 +632,13 @@ def main():
     prof = S.profile_read()
 
     ms_per_step = reduce_max(dist, (t1 - t0) * 1e3 / args.steps)
+
+    # N > 1: prove, outside the timed region, that RCCL connects all N ranks (one communicator + one barrier); the
+    # headline data path itself has no collective.  AFTER the measurement: a fabric that wedges half-way can leave
+    # RCCL kernels spinning on the device, and those must not sit beside the timed steps.
+    rccl_ranks, rccl_note = (None, None)
+    if world > 1:
+        rccl_ranks, rccl_note = rccl_probe(S, dist, rank, world, ndev)
 
     if rank == 0:
         mpix_step = world * F * n_out / 1e6
