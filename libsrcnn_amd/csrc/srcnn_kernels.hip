@@ -273,8 +273,8 @@ constexpr int rs_lds_bytes(int np, int maxt, int sr, int lw)
 
 // One tile row of the vertical pass with a compile-time tap count: source rows rb .. rb+CNT-1 of the patch are LW floats
 // apart, so every ds_read after the first address is an immediate offset.  Same products, same order as k_resample_cols.
-template <int CNT, int NP, int MAXT, int LW>
-__device__ __forceinline__ void rs_vertical_row(const float* raw, int raw_plane, float* midrow, const double* vwr, int rb, int cn, int lane)
+template <int CNT, int NP, int MAXT, int LW, class MID = float>
+__device__ __forceinline__ void rs_vertical_row(const float* raw, int raw_plane, MID* midrow, const double* vwr, int rb, int cn, int lane)
 {
     double wg[CNT];
 #pragma unroll
@@ -289,7 +289,7 @@ __device__ __forceinline__ void rs_vertical_row(const float* raw, int raw_plane,
             double acc = 0.0;
 #pragma unroll
             for (int t = 0; t < CNT; ++t) acc = acc + wg[t] * (double)xs[t];
-            midrow[p * RS_TH * LW + c] = (float)acc;
+            midrow[p * RS_TH * LW + c] = (MID)(float)acc;       // rounded to fp32 like the reference's intermediate image
         }
     }
 }
@@ -491,6 +491,177 @@ __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
             }
         }
         // the wave's own next vertical pass overwrites its intermediate rows: its lanes must be done reading them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rs2d_dma: the plane -> plane member of the family with the source patch moved by LDS-DMA (global_load_lds_dword: no
+// VGPR destination), ONE TILE AHEAD of the arithmetic.  k_rs2d asks for a tile's patch at the top of the tile and then
+// waits for it; holding the next patch in registers instead costs a wave per SIMD (see above).  The DMA needs neither:
+// while tile s is computed, tile s+1's patch lands in the other LDS buffer.  A wave moves patch rows wv, wv+4, ...; one
+// wave-instruction carries 64 consecutive source columns of one row (the LDS destination of a DMA is wave-uniform base +
+// lane * 4, which is exactly a row segment of the [row][LW] patch).  The DMA is an asm statement (hipcc would otherwise
+// wait for it before the first ds_read that follows); its completion is awaited explicitly before the tile's barrier.
+// Same arithmetic, same order as k_rs2d<0>: bit-identical.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rs_dma_dword(const float* gsrc, const float* lds_dst)
+{
+    unsigned keep;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+// wave-uniform table entries through the scalar cache (the tables are written long before any launch that reads them)
+__device__ __forceinline__ int rs_sload(const int* p, int i)
+{
+    return reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<uintptr_t>(p))[i];
+}
+
+template <int MAXT, int LW>
+__global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
+{
+    constexpr int TH = RS_TH;
+    constexpr int RPT = TH / 4;
+    constexpr int ZC = LW - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
+    double* vw2 = reinterpret_cast<double*>(rs_lds);           // [2][TH][MAXT]
+    int* vf2 = reinterpret_cast<int*>(vw2 + 2 * TH * MAXT);    // [2][TH]
+    int* vn2 = vf2 + 2 * TH;                                   // [2][TH]
+    double* mid = reinterpret_cast<double*>(vn2 + 2 * TH);     // [TH][LW]  fp32-rounded values, kept as doubles (see below)
+    float* raw2 = reinterpret_cast<float*>(mid + TH * LW);     // [2][sr][LW]
+    const int raw_plane = a.sr * LW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0t = blockIdx.x * 256;
+    const int xl = min(x0t + 256, a.dst_w) - 1;
+    const int c0 = rs_sload(a.hfirst, x0t), cn = rs_sload(a.hfirst, xl) + rs_sload(a.htaps, xl) - c0;
+    const int chunks = (cn + 63) >> 6;
+
+    const double* hp[4][MAXT];
+    double w[4][MAXT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // a lane owns columns 2*lane, 2*lane+1 of each 128-column half of the tile: neighbouring lanes then read
+        // neighbouring intermediate samples (for a 2x up-scale; four adjacent columns per lane put the lanes two dwords apart: a
+        // two-way LDS bank conflict on every horizontal tap)
+        const int xc = min(x0t + 128 * (j >> 1) + 2 * lane + (j & 1), a.dst_w - 1);
+        const int s0 = a.hfirst[xc] - c0, n = a.htaps[xc];
+        const double* wr = a.hwt + (size_t)xc * a.hstride;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            w[j][t] = t < n ? wr[t] : 0.0;
+            hp[j][t] = mid + wv * LW + (t < n ? s0 + t : ZC);
+        }
+    }
+    if (tid < TH) mid[tid * LW + ZC] = 0.0;
+
+    // this thread's slot of a tile's vertical weight table, fetched one tile ahead like the patch
+    const int wr_r = tid / MAXT, wr_t = tid - wr_r * MAXT;
+    double wreg = 0.0;
+    int freg = 0, nreg = 0;
+    auto fetch = [&](int sub) {
+        const int ry0 = (blockIdx.y * a.tpb + sub) * TH;
+        const int rows = min(TH, a.dst_rows - ry0);
+        const int y0 = a.dst_row0 + ry0, yl = y0 + rows - 1;
+        const int vmin = rs_sload(a.vfirst, y0), nsrc = rs_sload(a.vfirst, yl) + rs_sload(a.vtaps, yl) - vmin;
+        if (tid < TH * MAXT && wr_r < rows) {                  // three independent loads; the tap-count select happens at the use
+            const int y = y0 + wr_r;
+            nreg = a.vtaps[y];
+            freg = a.vfirst[y] - vmin;
+            wreg = a.vwt[(size_t)y * a.vstride + min(wr_t, a.vstride - 1)];
+        }
+        float* raw = raw2 + (sub & 1) * raw_plane;
+        const float* g = a.src_plane + (size_t)vmin * a.src_w + c0 + lane;
+        for (int r = wv; r < nsrc; r += 4)
+            for (int ch = 0; ch < chunks; ++ch)
+                if (ch * 64 + lane < cn) rs_dma_dword(g + (size_t)r * a.src_w + ch * 64, raw + r * LW + ch * 64);
+    };
+
+    const int xa = x0t + 2 * lane, xb = xa + 128;
+    fetch(0);
+    for (int sub = 0; sub < a.tpb; ++sub) {
+        const int ry0 = (blockIdx.y * a.tpb + sub) * TH;
+        if (ry0 >= a.dst_rows) break;
+        const int rows = min(TH, a.dst_rows - ry0);
+        double* vw = vw2 + (sub & 1) * TH * MAXT;
+        int* vf = vf2 + (sub & 1) * TH;
+        int* vn = vn2 + (sub & 1) * TH;
+        const float* raw = raw2 + (sub & 1) * raw_plane;
+        if (tid < TH * MAXT && wr_r < rows) {
+            vw[tid] = wr_t < nreg ? wreg : 0.0;
+            if (wr_t == 0) { vf[wr_r] = freg; vn[wr_r] = nreg; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the tile's patch has landed
+        __syncthreads();                                        // ... and so has everybody else's; tile sub-1 is finished everywhere
+        if (sub + 1 < a.tpb && ry0 + TH < a.dst_rows) fetch(sub + 1);
+
+        // vertical pass.  Full 64-column sweeps row by row (wave-uniform tap count -> unrolled body); what is left of a row
+        // (7 of 135 columns for a 2x up-scale: a sweep with 7 lanes at work) is done for the wave's four rows in ONE sweep,
+        // 16 lanes per row, with per-lane weights and a select instead of the wave-uniform tap count.
+        const int full = cn & ~63, rem = cn - full;
+        const bool tail = rem > 0 && rem <= 16;
+        const int cv = tail ? full : cn;
+        for (int r = wv; r < rows; r += 4) {
+            const int rb = __builtin_amdgcn_readfirstlane(vf[r]), cnt = __builtin_amdgcn_readfirstlane(vn[r]);
+            double* mrow = mid + r * LW;
+            const double* vwr = vw + r * MAXT;
+            switch (cnt) {
+#define RS_V(N) case N: if constexpr (N <= MAXT) rs_vertical_row<N, 1, MAXT, LW, double>(raw, raw_plane, mrow, vwr, rb, cv, lane); break;
+            RS_V(1) RS_V(2) RS_V(3) RS_V(4) RS_V(5) RS_V(6) RS_V(7) RS_V(8)
+#undef RS_V
+            default: break;
+            }
+        }
+        if (tail) {
+            const int r = wv + 4 * (lane >> 4), c = full + (lane & 15);
+            if (r < rows && c < cn) {
+                const int rb = vf[r], cnt = vn[r];
+                const double* vwr = vw + r * MAXT;
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {               // taps beyond the row's count: weight 0.0 (stored so) times a 0.0 sample
+                    const bool on = t < cnt;
+                    const float xv = raw[(rb + (on ? t : 0)) * LW + c];
+                    acc = acc + vwr[t] * (double)(on ? xv : 0.f);
+                }
+                mid[r * LW + c] = (double)(float)acc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (xa < a.dst_w) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = wv + 4 * k;
+                if (r >= rows) break;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double xs[MAXT];       // intermediate samples are stored widened: one conversion per sample, not per tap
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t) xs[t] = hp[j][t][4 * k * LW];
+                    double acc = 0.0;
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t) acc = acc + w[j][t] * xs[t];
+                    o[j] = (float)acc;
+                }
+                float* dr = a.dst + (size_t)(ry0 + r) * a.dst_w;
+                if (a.vec) {
+                    *reinterpret_cast<float2*>(dr + xa) = make_float2(o[0], o[1]);
+                    if (xb < a.dst_w) *reinterpret_cast<float2*>(dr + xb) = make_float2(o[2], o[3]);
+                } else {
+                    if (xa < a.dst_w) dr[xa] = o[0];
+                    if (xa + 1 < a.dst_w) dr[xa + 1] = o[1];
+                    if (xb < a.dst_w) dr[xb] = o[2];
+                    if (xb + 1 < a.dst_w) dr[xb + 1] = o[3];
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1438,6 +1609,9 @@ hipError_t rs2d_prepare()
         if (e != hipSuccess && err == hipSuccess) err = e;
     };
     rs2d_variants<0, 3, false>(raise);
+#define RS_ONE(MT, LW_) raise(reinterpret_cast<const void*>(&k_rs2d_dma<MT, LW_>), MT, LW_);
+    RS_ONE(3, 136) RS_ONE(5, 136) RS_ONE(8, 136) RS_ONE(3, 272) RS_ONE(5, 272) RS_ONE(8, 272)
+#undef RS_ONE
     rs2d_variants<1, 3, false>(raise); rs2d_variants<1, 4, false>(raise);
     rs2d_variants<2, 3, false>(raise); rs2d_variants<2, 3, true>(raise);
     rs2d_variants<2, 4, false>(raise); rs2d_variants<2, 4, true>(raise);
@@ -1467,7 +1641,16 @@ bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w
     a.vfirst = tv.first; a.vtaps = tv.taps; a.vwt = tv.weight; a.vstride = tv.stride;
     a.hfirst = th.first; a.htaps = th.taps; a.hwt = th.weight; a.hstride = th.stride;
     a.vec = (dst_w % 4 == 0) && aligned_to(dst, 16);
-    if (src.plane) rs2d_dispatch<0, 3, false>(p, a, s);
+    static const bool dma = [] { const char* e = getenv("SRCNN_RS_DMA"); return !(e && e[0] == '0'); }();
+    const size_t lds_dma = p.lds + (size_t)RS_TH * p.lw * 4;  // its intermediate rows are doubles
+    if (src.plane && dma && lds_dma <= (size_t)RS_LDS_LIMIT) {
+        const dim3 grid(p.gx, p.gy), block(256);
+#define RS_GO(MT, LW_) hipLaunchKernelGGL((k_rs2d_dma<MT, LW_>), grid, block, lds_dma, s, a)
+        if (p.lw == 136) { if (p.maxt == 3) RS_GO(3, 136); else if (p.maxt == 5) RS_GO(5, 136); else RS_GO(8, 136); }
+        else             { if (p.maxt == 3) RS_GO(3, 272); else if (p.maxt == 5) RS_GO(5, 272); else RS_GO(8, 272); }
+#undef RS_GO
+    }
+    else if (src.plane) rs2d_dispatch<0, 3, false>(p, a, s);
     else if (src.depth == 3) rs2d_dispatch<1, 3, false>(p, a, s);
     else rs2d_dispatch<1, 4, false>(p, a, s);
     return true;
