@@ -22,6 +22,7 @@
 // VALU kernels read them as SGPR operands (wave-uniform addresses -> s_load); the MFMA kernels re-stage
 // them into LDS per block in operand (lane) order.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -505,7 +506,8 @@ __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
 // wave-instruction carries 64 consecutive source columns of one row (the LDS destination of a DMA is wave-uniform base +
 // lane * 4, which is exactly a row segment of the [row][LW] patch).  The DMA is an asm statement (hipcc would otherwise
 // wait for it before the first ds_read that follows); its completion is awaited explicitly before the tile's barrier.
-// Same arithmetic, same order as k_rs2d<0>: bit-identical.
+// Same arithmetic, same order as k_rs2d<0>: bit-identical.  Measured on an 8K plane: 0.056 ms = 3.0 TB/s (k_rs2d<0>:
+// 0.072 ms); the steps are listed in DESIGN.md 4.3.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rs_dma_dword(const float* gsrc, const float* lds_dst)
 {
@@ -543,6 +545,7 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
 
     const double* hp[4][MAXT];
     double w[4][MAXT];
+    int nmax = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // a lane owns columns 2*lane, 2*lane+1 of each 128-column half of the tile: neighbouring lanes then read
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
         const int xc = min(x0t + 128 * (j >> 1) + 2 * lane + (j & 1), a.dst_w - 1);
         const int s0 = a.hfirst[xc] - c0, n = a.htaps[xc];
         const double* wr = a.hwt + (size_t)xc * a.hstride;
+        nmax = max(nmax, n);
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             w[j][t] = t < n ? wr[t] : 0.0;
@@ -558,6 +562,9 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
         }
     }
     if (tid < TH) mid[tid * LW + ZC] = 0.0;
+    // The table's widest column sets MAXT, but it is usually an edge case (2x Mitchell: 4 taps everywhere, 5 on two columns
+    // of 7680).  A wave none of whose columns uses the last tap skips it -- that tap would only add +0.0.
+    const bool short_taps = MAXT > 1 && __builtin_amdgcn_ballot_w64(nmax > MAXT - 1) == 0;
 
     // this thread's slot of a tile's vertical weight table, fetched one tile ahead like the patch
     const int wr_r = tid / MAXT, wr_t = tid - wr_r * MAXT;
@@ -634,7 +641,8 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (xa < a.dst_w) {
+        auto horizontal = [&](auto ntaps) {
+            constexpr int NT = decltype(ntaps)::value;
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 const int r = wv + 4 * k;
@@ -642,12 +650,12 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    double xs[MAXT];       // intermediate samples are stored widened: one conversion per sample, not per tap
+                    double xs[NT];         // intermediate samples are stored widened: one conversion per sample, not per tap
 #pragma unroll
-                    for (int t = 0; t < MAXT; ++t) xs[t] = hp[j][t][4 * k * LW];
+                    for (int t = 0; t < NT; ++t) xs[t] = hp[j][t][4 * k * LW];
                     double acc = 0.0;
 #pragma unroll
-                    for (int t = 0; t < MAXT; ++t) acc = acc + w[j][t] * xs[t];
+                    for (int t = 0; t < NT; ++t) acc = acc + w[j][t] * xs[t];
                     o[j] = (float)acc;
                 }
                 float* dr = a.dst + (size_t)(ry0 + r) * a.dst_w;
@@ -661,6 +669,10 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
                     if (xb + 1 < a.dst_w) dr[xb + 1] = o[3];
                 }
             }
+        };
+        if (xa < a.dst_w) {
+            if (short_taps) horizontal(std::integral_constant<int, (MAXT > 1 ? MAXT - 1 : 1)>{});
+            else horizontal(std::integral_constant<int, MAXT>{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1643,7 +1655,7 @@ bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w
     a.vec = (dst_w % 4 == 0) && aligned_to(dst, 16);
     static const bool dma = [] { const char* e = getenv("SRCNN_RS_DMA"); return !(e && e[0] == '0'); }();
     const size_t lds_dma = p.lds + (size_t)RS_TH * p.lw * 4;  // its intermediate rows are doubles
-    if (src.plane && dma && lds_dma <= (size_t)RS_LDS_LIMIT) {
+    if (src.plane && dma && lds_dma <= (size_t)64 * 1024) {    // (M0 carries the DMA's LDS address: stay inside what a 16-bit field reaches)
         const dim3 grid(p.gx, p.gy), block(256);
 #define RS_GO(MT, LW_) hipLaunchKernelGGL((k_rs2d_dma<MT, LW_>), grid, block, lds_dma, s, a)
         if (p.lw == 136) { if (p.maxt == 3) RS_GO(3, 136); else if (p.maxt == 5) RS_GO(5, 136); else RS_GO(8, 136); }

@@ -34,6 +34,8 @@ def short(name):
         tier = " [strict]"
     elif "<false" in name:
         tier = " [fast tier]"
+    if "k_rs2d_dma" in name:
+        return "k_rs2d_dma [plane -> plane, LDS-DMA]"
     if "k_rs2d<" in name:
         kind = name.split("k_rs2d<")[1].split(",")[0].strip()
         return {"0": "k_rs2d [plane -> plane]", "1": "k_rs2d [RGB -> upscaled Y]", "2": "k_rs2d [fused chroma resample + colour merge]"}.get(kind, "k_rs2d")
