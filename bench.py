@@ -167,6 +167,23 @@ def process_srcnn_wall(S):
         out[name] = {"best_ms": round(min(ts) * 1e3, 2), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 2),
                      "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
                      "host_cpu_ms_per_call": round(sorted(cs)[len(cs) // 2] * 1e3, 2)}
+    # The same image through the C ABI's srcnn_process_u8 into a caller-owned, REUSED result buffer: what a caller that
+    # upscales a sequence should use -- no fresh 100 MB of pages per call (tools/concurrent_probe.py has the multi-caller runs).
+    h, w = 2160, 3840
+    img = synth_rgb(h, w, 0x5C0DE100)
+    res = np.empty((2 * h, 2 * w, 3), np.uint8)
+    ts = []
+    for it in range(9):
+        t0 = time.perf_counter()
+        rc = L.srcnn_process_u8(img.ctypes.data, w, h, 3, 2.0, 2, res.ctypes.data, None)
+        dt = time.perf_counter() - t0
+        assert rc == 0, rc
+        if it:
+            ts.append(dt)
+    out["3840x2160_rgb_reused_result_buffer"] = {
+        "best_ms": round(min(ts) * 1e3, 2), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 2),
+        "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
+        "note": "srcnn_process_u8: host u8 RGB in -> caller-owned, reused host u8 RGB out, calls back to back"}
     out["note"] = "host u8 RGB in -> host u8 RGB out through the drop-in symbol; includes H2D, colour split, chroma " \
                   "resample, Y path, merge, D2H and the new[] of the result"
     return out
