@@ -19,6 +19,8 @@ def main(n=150, seed=1234):
     bad = 0
     for k in range(n):
         h, w = int(rng.integers(1, 120)), int(rng.integers(1, 260))
+        if rng.random() < 0.1:                          # a tenth of the cases span many column tiles / several row tiles
+            h, w = int(rng.integers(100, 500)), int(rng.integers(300, 1500))
         kind = "noise" if rng.random() < 0.5 else "smooth"
         y = synth.plane(h, w, int(rng.integers(0, 1 << 30)), kind)
         if rng.random() < 0.15:
@@ -36,11 +38,13 @@ def main(n=150, seed=1234):
                 dw += 1
             got, want, what = S.y_path(y, dw, dh, filt), o.y_path(y, dw, dh, filt), "filter %d -> %dx%d" % (filt, dw, dh)
         ok = got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        if k % 50 == 49:
+            print("  ... %d float cases done" % (k + 1), flush=True)
         if not ok:
             bad += 1
             d = np.abs(got.astype(np.float64) - want) if got.shape == want.shape else np.array([np.inf])
             print("MISMATCH case %d: %dx%d %s %s max|d|=%g" % (k, w, h, kind, what, float(np.nanmax(d))))
-    print("campaign: %d float cases, %d mismatches" % (n, bad))
+    print("campaign: %d float cases, %d mismatches" % (n, bad), flush=True)
     return bad
 
 
