@@ -210,6 +210,28 @@ def pcie_inclusive(S, frames=16):
                     "threads) per frame: the helper threads block, they do not spin; never the headline value"}
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE line on stdout.  Libraries print there too (gloo's "[Gloo] Rank 0 is connected to ..." under
+    torch.distributed.run, RCCL/ROCm notices): from here on fd 1 of this rank IS stderr, and only emit() writes to the
+    real stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (line + "\n").encode()
+    fd = _RESULT_FD if _RESULT_FD is not None else 1
+    sys.stdout.flush()
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -500,13 +522,13 @@ def side_workload(args):
         if note:
             extra["rccl_note"] = note
     if rank == 0:
-        print(json.dumps({"metric": METRIC + (" incl. PCIe" if args.workload == "host-stream" else ""),
+        emit(json.dumps({"metric": METRIC + (" incl. PCIe" if args.workload == "host-stream" else ""),
                           "value": round(mpix_step / (ms * 1e-3), 2),
                           "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(ms, 4), "higher_is_better": True,
                           "scaling": "strong" if args.workload == "tiled8k" else "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "config": {"workload": label, "mode": "strict"},
-                          "host_cpu_s_per_step_max_rank": round(cpu_s, 5), **extra}), flush=True)
+                          "host_cpu_s_per_step_max_rank": round(cpu_s, 5), **extra}))
     barrier()
     if cleanup is not None:
         cleanup()
@@ -529,11 +551,11 @@ def dry_run_line(args, rank, world, dist):
         seen = [(rank, os.getpid())]
     t = reduce_max(dist, float(rank + 1))
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": None, "unit": "MPix/s", "n_gpus": world, "steps": args.steps,
+        emit(json.dumps({"metric": METRIC, "value": None, "unit": "MPix/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "ranks_seen": [r for r, _ in seen],
                           "distinct_pids": len({p for _, p in seen}), "max_over_ranks_check": t,
                           "parent_pid": os.getppid(), "host": socket.gethostname(),
-                          "config": {"workload": args.workload}}), flush=True)
+                          "config": {"workload": args.workload}}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -589,6 +611,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started without a launcher: become the launcher.  Nothing in this process has touched (or will touch) the GPU.
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    claim_stdout()
     if os.environ.get("SRCNN_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and args.dry_run:
         sys.exit(7)                        # test hook (tests/test_bench_launcher.py): a rank that dies before the rendezvous
     if args.workload != "frames":
@@ -749,7 +772,7 @@ def main():
             except Exception as e:                                # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "MPix/s", "cores": physical_cores(), "kind": "port",
                                        "sample": "failed: %s" % e}
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
     barrier()
     if world > 1 and rccl_ranks is not None:

@@ -52,6 +52,9 @@ def test_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     line, = _json_lines(r.stdout)
     assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1]
+    # ONE line on stdout means one line: what libraries print there (gloo's "[Gloo] Rank 0 is connected to 1 peer ranks")
+    # must not sit next to the result
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout
 
 
 def test_failed_rank_fails_the_launch():
