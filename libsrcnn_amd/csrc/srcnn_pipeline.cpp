@@ -45,6 +45,8 @@ bool is_pinned(const void* p)
 // huge pages it runs at memory speed (1.5 ms) -- profiles/r03_host_out_probe.txt.  A hint only: harmless where THP is off.
 void hint_huge_pages(void* p, size_t n)
 {
+    static const bool off = [] { const char* e = getenv("SRCNN_THP"); return e && atoi(e) == 0; }();   // A/B runs: a host with THP = never
+    if (off) return;
     const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
     const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
     if (e > a + (4u << 20)) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);
@@ -58,13 +60,32 @@ void hint_huge_pages(void* p, size_t n)
 // fan-out memcpy would otherwise pay band by band, the last ones in the call's tail.  MADV_POPULATE_WRITE (Linux 5.14) does
 // not touch the data, so it is safe beside a memcpy that already writes the same range; where it is not available nothing
 // is done (the memcpy faults the pages itself, as before).
-void prefault_pages(void* p, size_t n)
+void prefault_range(uintptr_t a, uintptr_t e)
 {
-    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
-    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
     const size_t chunk = 8u << 20;
     for (uintptr_t q = a; q < e; q += chunk)
         if (madvise(reinterpret_cast<void*>(q), std::min<size_t>(chunk, e - q), MADV_POPULATE_WRITE) != 0) return;
+}
+
+// `threads` workers, each on a contiguous share of the range, in address order within a share; the first share is the one
+// the fan-out needs first.  One worker populates 100 MB in 3.8 ms into huge pages and 6 ms into 4 KB pages, four in 1.3 / 2.5 ms
+// (profiles/r03_host_out_probe.txt): with 4 KB pages a lone worker is only barely ahead of the device.
+void prefault_pages(void* p, size_t n, int threads = 1)
+{
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
+    if (e <= a) return;
+    threads = std::max(1, std::min<int>(threads, (int)((e - a) >> 24) + 1));      // at least 16 MB per worker
+    if (threads == 1) { prefault_range(a, e); return; }
+    const uintptr_t share = (((e - a) / threads) + 4095) & ~uintptr_t(4095);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) {
+        const uintptr_t b0 = std::min(e, a + t * share), b1 = std::min(e, b0 + share);
+        try { pool.emplace_back([=] { prefault_range(b0, t + 1 == threads ? e : b1); }); }
+        catch (...) { prefault_range(b0, t + 1 == threads ? e : b1); }
+    }
+    prefault_range(a, std::min(e, a + share));
+    for (auto& t : pool) t.join();
 }
 
 constexpr unsigned kBlockingEvent = hipEventDisableTiming | hipEventBlockingSync;   // host waits sleep, they do not spin
@@ -370,7 +391,8 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         hint_huge_pages(o0, out_bytes);
         if (c0) hint_huge_pages(c0, share_px);
         static const bool no_prefault = [] { const char* e = getenv("SRCNN_PREFAULT"); return e && atoi(e) == 0; }();
-        if (!no_prefault) prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes); if (c0) prefault_pages(c0, share_px); });
+        static const int pf_threads = [] { const char* e = getenv("SRCNN_PREFAULT_THREADS"); return e ? std::max(1, atoi(e)) : 1; }();
+        if (!no_prefault) prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes, pf_threads); if (c0) prefault_pages(c0, share_px); });
     }
     struct JoinPrefault {                                      // whatever path leaves this function: the helper is joined first
         std::thread& t; bool& on;
