@@ -13,14 +13,15 @@
 typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int CH = 16;
 
-enum Mode { FMA32, MULADD32, PKFMA, PKMULADD, MUL_CVT_ADD64, ADD64, FMA64, CVT64, MULADD32_SGPR, PKMULADD_SGPR, MUL64, MULADD64, FMA0ADD64, NMODES };
+enum Mode { FMA32, MULADD32, PKFMA, PKMULADD, MUL_CVT_ADD64, ADD64, FMA64, CVT64, MULADD32_SGPR, PKMULADD_SGPR, MUL64, MULADD64, FMA0ADD64, PKMUL_CVT_ADD64, CVT_ADD64, CVT_F64_F32, NMODES };
 const char* kNames[NMODES] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_pk_fma_f32", "v_pk_mul_f32+v_pk_add_f32",
                               "v_mul_f32+v_cvt_f64_f32+v_add_f64", "v_add_f64", "v_fma_f64", "v_cvt_f64_f32+v_cvt_f32_f64",
                               "v_mul_f32(sgpr)+v_add_f32", "v_pk_mul_f32(sgpr)+v_pk_add_f32",
-                              "v_mul_f64", "v_cvt_f64_f32+v_mul_f64+v_add_f64 (resampler tap)", "v_cvt_f64_f32+v_fma_f64(w,x,0)+v_add_f64"};
+                              "v_mul_f64", "v_cvt_f64_f32+v_mul_f64+v_add_f64 (resampler tap)", "v_cvt_f64_f32+v_fma_f64(w,x,0)+v_add_f64",
+                              "v_pk_mul_f32 + 2 v_cvt_f64_f32 + 2 v_add_f64 (conv3 pair)", "v_cvt_f64_f32+v_add_f64", "v_cvt_f64_f32"};
 // VALU instructions per chain step, and useful "MAC-equivalents" (multiply-accumulates) per chain step
-const int kInstr[NMODES] = {1, 2, 1, 2, 3, 1, 1, 2, 2, 2, 1, 3, 3};
-const int kMacs[NMODES]  = {1, 1, 2, 2, 1, 1, 1, 1, 1, 2, 1, 1, 1};
+const int kInstr[NMODES] = {1, 2, 1, 2, 3, 1, 1, 2, 2, 2, 1, 3, 3, 5, 2, 1};
+const int kMacs[NMODES]  = {1, 1, 2, 2, 1, 1, 1, 1, 1, 2, 1, 1, 1, 2, 1, 1};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, float a, float b, int iters, const float* __restrict__ wt)
@@ -65,6 +66,31 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b, int iters
 #pragma unroll
             for (int c = 0; c < CH; ++c) { float p = v[c] * a; acc[c] = acc[c] + (double)p; v[c] = p; }
         double s = 0; for (int c = 0; c < CH; ++c) s += acc[c];
+        out[tid] = (float)s;
+    } else if constexpr (MODE == PKMUL_CVT_ADD64) {
+        // conv3's inner step as the kernel issues it: one packed product for two taps, two conversions, two fp64 adds
+        double acc[CH], acc2[CH]; float2v v[CH]; const float2v av = {a, a * 1.0001f};
+        for (int c = 0; c < CH; ++c) { acc[c] = tid * 1e-9 + c; acc2[c] = c; v[c] = float2v{tid * 1e-9f + c, tid * 2e-9f + c}; }
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { float2v p = v[c] * av; acc[c] = acc[c] + (double)p.x; acc2[c] = acc2[c] + (double)p.y; v[c] = p; }
+        double s = 0; for (int c = 0; c < CH; ++c) s += acc[c] + acc2[c];
+        out[tid] = (float)s;
+    } else if constexpr (MODE == CVT_ADD64) {
+        double acc[CH]; float v[CH];
+        for (int c = 0; c < CH; ++c) { acc[c] = tid * 1e-9 + c; v[c] = tid * 1e-9f + c; }
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { float x = v[c]; asm volatile("" : "+v"(x)); acc[c] = acc[c] + (double)x; }
+        double s = 0; for (int c = 0; c < CH; ++c) s += acc[c];
+        out[tid] = (float)s;
+    } else if constexpr (MODE == CVT_F64_F32) {
+        float v[CH]; double d[CH];
+        for (int c = 0; c < CH; ++c) { v[c] = tid * 1e-9f + c; d[c] = 0; }
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { float x = v[c]; asm volatile("" : "+v"(x)); d[c] = (double)x; asm volatile("" : "+v"(d[c])); }
+        double s = 0; for (int c = 0; c < CH; ++c) s += d[c];
         out[tid] = (float)s;
     } else if constexpr (MODE == ADD64) {
         double acc[CH]; const double bd = b;
@@ -184,6 +210,9 @@ int main(int argc, char** argv)
         run<MUL64>(b, cus, ghz, d_out, d_w);
         run<MULADD64>(b, cus, ghz, d_out, d_w);
         run<FMA0ADD64>(b, cus, ghz, d_out, d_w);
+        run<PKMUL_CVT_ADD64>(b, cus, ghz, d_out, d_w);
+        run<CVT_ADD64>(b, cus, ghz, d_out, d_w);
+        run<CVT_F64_F32>(b, cus, ghz, d_out, d_w);
         printf("\n");
     }
     return 0;
