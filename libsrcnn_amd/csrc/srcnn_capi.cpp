@@ -9,6 +9,7 @@
 // There is deliberately no CPU compute path in this file: if HIP is unusable the calls fail.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -20,6 +21,7 @@
 #include <thread>
 
 #include "resample_table.hpp"
+#include <chrono>
 #include "srcnn_host.hpp"
 
 namespace srcnn {
@@ -408,6 +410,51 @@ int grow_pinned(Ctx& cx, unsigned char*& p, size_t& have, size_t want)
     if (!p) return SRCNN_E_DEVMEM;
     have = want;
     return SRCNN_OK;
+}
+
+namespace {
+// The naps are 20 us (50 us after the first 2 ms).  The kernel rounds a sleep up by the thread's timer slack, 50 us by default,
+// which would make every nap 70+ us; the slack is lowered for the duration of the wait only and put back afterwards.
+template <class Q>
+hipError_t poll_until_ready(Q&& query)
+{
+    hipError_t r;
+    for (int i = 0; i < 64; ++i)
+        if ((r = query()) != hipErrorNotReady) return r;
+    const int slack = prctl(PR_GET_TIMERSLACK);
+    if (slack > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL);
+    for (int n = 0;; ++n) {
+        std::this_thread::sleep_for(std::chrono::microseconds(n < 100 ? 20 : 50));
+        if ((r = query()) != hipErrorNotReady) break;
+    }
+    if (slack > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack);
+    return r;
+}
+bool spin_waits()
+{
+    static const bool on = [] { const char* e = getenv("SRCNN_SPIN_WAIT"); return e && atoi(e) != 0; }();
+    return on;
+}
+}  // namespace
+
+hipError_t wait_event(hipEvent_t e, std::mutex* query_guard)
+{
+    if (spin_waits()) return hipEventSynchronize(e);
+    const hipError_t r = poll_until_ready([&] {
+        if (!query_guard) return hipEventQuery(e);
+        std::lock_guard<std::mutex> lk(*query_guard);
+        return hipEventQuery(e);
+    });
+    (void)hipGetLastError();               // the "not ready" answers are not errors
+    return r;
+}
+
+hipError_t wait_stream(hipStream_t s)
+{
+    if (spin_waits()) return hipStreamSynchronize(s);
+    const hipError_t r = poll_until_ready([&] { return hipStreamQuery(s); });
+    (void)hipGetLastError();
+    return r;
 }
 
 void parallel_memcpy(void* dst, const void* src, size_t n)

@@ -260,6 +260,17 @@ std::vector<unsigned> tiled_cuts(unsigned out_w, unsigned out_h, int rank, int n
 // touch, which a single thread does at only a few GB/s.
 void parallel_memcpy(void* dst, const void* src, size_t n);
 
+// Host waits.  On this runtime hipEventSynchronize / hipStreamSynchronize hold a core at 100 % for the whole wait, whatever the
+// event's flags -- hipEventBlockingSync included; only the process-wide hipDeviceScheduleBlockingSync changes that, and that
+// flag is the host application's to set (tools/ubench/wait_cost.hip, profiles/r03_wait_cost.txt: a 5 ms wait costs 5.0 ms of
+// CPU either way, 0.03 ms when polled).  The library's threads wait for milliseconds at a time, several of them per call, so
+// they poll: a burst of queries for waits that are (almost) over, then sleep-and-query in 20..100 us naps.
+// SRCNN_SPIN_WAIT=1 restores the runtime's own waits (A/B runs).
+// query_guard: held around every query.  A thread that captures a stream into a graph takes the same mutex for the span of
+// the capture: an event query that lands inside another thread's capture of the stream the event belongs to ends that capture.
+hipError_t wait_event(hipEvent_t e, std::mutex* query_guard = nullptr);
+hipError_t wait_stream(hipStream_t s);
+
 // An ordered hand-off between a producer and ONE consumer thread (replaces the round-2 yield() spin loops): the producer
 // publishes "items [0, n) are ready", the consumer blocks in wait_for(i) until item i is ready or the hand-off is
 // cancelled.  Nobody spins.

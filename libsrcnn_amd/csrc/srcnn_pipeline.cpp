@@ -116,7 +116,7 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
         for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out})
             if (!rc && !*e && hipEventCreateWithFlags(e, kBlockingEvent) != hipSuccess) rc = fail(SRCNN_E_HIP, "event create");
         if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) {     // shape or mode changed: drop the graph first,
-            if (sl.exec) { (void)hipStreamSynchronize(cx.slots[0].st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
+            if (sl.exec) { (void)wait_stream(cx.slots[0].st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
             sl.ws.frozen = false;                                          // then its buffers may move again
             sl.graph_tables.clear();
             sl.tables.clear();
@@ -134,9 +134,10 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
     Handoff launched;      // frames whose kernels have been queued (e_k recorded)
     Handoff copied;        // frames whose D2H has been queued (e_out recorded)
     std::atomic<int> copy_err{0};
+    std::mutex capture_mu; // the copier's event queries stay out of the kernel stream's graph captures
     auto copy_frame = [&](unsigned f) {
         StreamSlot& sl = cx.slots[f % nslots];
-        if (hipEventSynchronize(sl.e_k) != hipSuccess ||
+        if (wait_event(sl.e_k, &capture_mu) != hipSuccess ||
             hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.cst) != hipSuccess ||
             hipEventRecord(sl.e_out, sl.cst) != hipSuccess) copy_err = 1;
         copied.publish(f + 1);
@@ -160,11 +161,11 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
             // the slot's previous frame: its kernels are done (the copier saw e_k) once its D2H has been queued; wait for
             // that D2H to finish before din / dout are reused
             if (threaded && !copied.wait_for(f - nslots)) { rc = fail(SRCNN_E_HIP, "frame stream cancelled"); break; }
-            if (hipEventSynchronize(sl.e_out) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
+            if (wait_event(sl.e_out) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
         }
         // frame in: also resolved on the host (the previous frame's kernels keep the device busy meanwhile)
         if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.cst) != hipSuccess ||
-            hipEventRecord(sl.e_in, sl.cst) != hipSuccess || hipEventSynchronize(sl.e_in) != hipSuccess) {
+            hipEventRecord(sl.e_in, sl.cst) != hipSuccess || wait_event(sl.e_in) != hipSuccess) {
             rc = fail(SRCNN_E_HIP, "H2D"); break;
         }
         if (use_graph && sl.uses >= 1 && !sl.exec) {
@@ -175,9 +176,12 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
             sl.ws.frozen = true;
             c.timing = false;              // event pairs cannot be timed inside a capture
             c.hold = &sl.graph_tables;
-            if (hipStreamBeginCapture(ks, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
-            if (!rc) rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
-            if (hipStreamEndCapture(ks, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
+            {
+                std::lock_guard<std::mutex> cap(capture_mu);
+                if (hipStreamBeginCapture(ks, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = fail(SRCNN_E_HIP, "begin capture");
+                if (!rc) rc = y_path_frame(c, sl.din, w, h, 2 * w, 2 * h, SRCNN_FILTER_BICUBIC, sl.dout);
+                if (hipStreamEndCapture(ks, &graph) != hipSuccess && !rc) rc = fail(SRCNN_E_HIP, "end capture");
+            }
             c.timing = true;
             c.hold = &sl.tables;
             if (!rc && hipGraphInstantiate(&sl.exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(SRCNN_E_HIP, "graph instantiate");
@@ -192,7 +196,7 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
                 // first.  Its workspace is frozen (pointers baked in), so an eager run that needs more scratch -- a larger
                 // srcnn_set_workspace_limit since the capture -- could not grow it; and nothing should keep a graph alive
                 // that the caller no longer asks for.  The next use_graph call captures again after one eager frame.
-                (void)hipStreamSynchronize(ks);
+                (void)wait_stream(ks);
                 (void)hipGraphExecDestroy(sl.exec);
                 sl.exec = nullptr;
                 sl.ws.frozen = false;
@@ -210,8 +214,8 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
     if (rc) launched.cancel();             // the copier stops at the first frame that was never launched
     if (threaded) copier.join();
     for (int i = 0; i < nslots; ++i) {
-        if (cx.slots[i].st) (void)hipStreamSynchronize(cx.slots[i].st);
-        if (cx.slots[i].cst) (void)hipStreamSynchronize(cx.slots[i].cst);
+        if (cx.slots[i].st) (void)wait_stream(cx.slots[i].st);
+        if (cx.slots[i].cst) (void)wait_stream(cx.slots[i].cst);
     }
     if (!rc && copy_err) rc = fail(SRCNN_E_HIP, "a device-to-host copy of the frame stream failed");
     return rc;
@@ -274,7 +278,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     {
         const size_t need = n * d + (size_t)(R1 - R0) * dw * (d + 1 + 4 + 8) + (size_t)C2N * dw * std::min<size_t>(R1 - R0, budget_band_rows(dw)) * 4;
         const size_t have = ws.footprint() + L.pin_in_n + L.pin_out_n;
-        if (have > (256u << 20) && have > 8 * need) { (void)hipStreamSynchronize(L.st); (void)hipStreamSynchronize(L.copy_st); L.release_buffers(); }
+        if (have > (256u << 20) && have > 8 * need) { (void)wait_stream(L.st); (void)wait_stream(L.copy_st); L.release_buffers(); }
     }
 
     // ---- which source rows does this share read?  (the Y path's vertical taps + halo, and the chroma taps) ----
@@ -426,7 +430,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if ((rc = run_band(R0, R1))) return rc;
         HIP_TRY(hipMemcpyAsync(J.out + (size_t)R0 * dw * d, d_out, out_bytes, hipMemcpyDeviceToHost, s));
         if (J.conv) HIP_TRY(hipMemcpyAsync(J.conv + (size_t)R0 * dw, d_conv, share_px, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(wait_stream(s));
         return SRCNN_OK;
     }
 
@@ -441,7 +445,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     Handoff enqueued;                       // bands whose kernels have been queued (their "computed" event recorded)
     auto d2h_band = [&](unsigned b) {
         const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
-        if (hipEventSynchronize(L.band_events[2 * b]) != hipSuccess ||
+        if (wait_event(L.band_events[2 * b]) != hipSuccess ||
             hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
             (J.conv && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess) ||
             hipEventRecord(L.band_events[2 * b + 1], L.copy_st) != hipSuccess) { copy_err = 1; return false; }
@@ -449,7 +453,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     };
     auto fan_band = [&](unsigned b) {
         TraceRange tf("srcnn fan-out band %u", b);
-        if (hipEventSynchronize(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
+        if (wait_event(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
         const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
         const size_t g0 = (size_t)cuts[b] * dw;
         parallel_memcpy(J.out + g0 * d, pin_rgb + p0 * d, pn * d);
@@ -493,7 +497,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         for (unsigned b = 0; b < nb; ++b) fan_band(b);            // the second helper could not be started: fan out here
     const auto t2 = now();
     // everything this call queued has completed by now (the helper waited for the last D2H event); these return at once
-    hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(L.copy_st);
+    hipError_t e1 = wait_stream(s), e2 = wait_stream(L.copy_st);
     if (launch_rc) return launch_rc;
     if (e1 != hipSuccess || e2 != hipSuccess || copy_err) return fail(SRCNN_E_HIP, "pipeline failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     HIP_TRY(hipGetLastError());
@@ -720,7 +724,7 @@ int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, fl
         };
         auto push = [&](unsigned i) -> int {
             if (is_root || cut[i + 1] <= cut[i]) return SRCNN_OK;
-            HIP_TRY(hipEventSynchronize(N.events[i]));
+            HIP_TRY(wait_event(N.events[i]));
             HIP_TRY(hipMemcpyPeerAsync(d_out + (size_t)cut[i] * dw, root->device, N.band + (size_t)(cut[i] - R0) * dw, cx.device,
                                        sizeof(float) * (size_t)(cut[i + 1] - cut[i]) * dw, N.copy_st));
             return SRCNN_OK;
@@ -733,8 +737,8 @@ int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, fl
         // wait for both queues on blocking events (8 workers spinning in hipStreamSynchronize would burn 8 host cores)
         HIP_TRY(hipEventRecord(N.events[nsub], N.st));
         HIP_TRY(hipEventRecord(N.events[nsub + 1], N.copy_st));
-        HIP_TRY(hipEventSynchronize(N.events[nsub]));
-        HIP_TRY(hipEventSynchronize(N.events[nsub + 1]));
+        HIP_TRY(wait_event(N.events[nsub]));
+        HIP_TRY(wait_event(N.events[nsub + 1]));
         return SRCNN_OK;
     };
     std::vector<std::thread> th(nctx);
