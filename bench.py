@@ -207,7 +207,7 @@ def pcie_inclusive(S, frames=16):
             "host_cpu_s_per_frame": round(min(cs) / F, 6), "wall_s_per_frame": round(min(ts) / F, 6),
             "note": "planar f32 Y frames in page-locked host memory, H2D + path + D2H overlapped over two slots "
                     "(srcnn_y_upscale2x_f32_stream, hipGraph per slot); host_cpu_s_per_frame = process CPU time (all "
-                    "threads) per frame: the helper threads block, they do not spin; never the headline value"}
+                    "threads) per frame: the helper threads sleep or poll, they do not spin; never the headline value"}
 
 
 _RESULT_FD = None

@@ -13,9 +13,10 @@
 //                                  band in sub-bands, and pushes every finished sub-band to the root while the next one
 //                                  computes (the single-process counterpart of the RCCL band gather).
 //
-// Every copy/kernel dependency that involves a copy engine is resolved on the HOST by a helper thread that BLOCKS
-// (hipEventSynchronize / condition variable): on this runtime a copy that waits device-side on another queue's event does
-// not overlap that queue's kernels (profiles/r02_stream_overlap.txt), and the round-2 yield() spin loops are gone.
+// Every copy/kernel dependency that involves a copy engine is resolved on the HOST by a helper thread: on this runtime a copy
+// that waits device-side on another queue's event does not overlap that queue's kernels (profiles/r02_stream_overlap.txt).
+// The helpers sleep on condition variables and POLL device events (wait_event / wait_stream, srcnn_host.hpp): the runtime's
+// own waits hold a core for the whole wait, hipEventBlockingSync or not (profiles/r03_wait_cost.txt).
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
@@ -88,7 +89,7 @@ void prefault_pages(void* p, size_t n, int threads = 1)
     for (auto& t : pool) t.join();
 }
 
-constexpr unsigned kBlockingEvent = hipEventDisableTiming | hipEventBlockingSync;   // host waits sleep, they do not spin
+constexpr unsigned kBlockingEvent = hipEventDisableTiming | hipEventBlockingSync;   // (the flag is honoured only under hipDeviceScheduleBlockingSync; our waits poll)
 
 // Start a helper thread; false (and nothing started) if the system refuses -- callers then run the work inline.
 template <class F>
@@ -130,7 +131,7 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
     // resolved on the HOST (see the file header; measured with tools/hs_probe.py, 4K frames: 12.2-12.4 ms per frame with
     // the D2H on the kernel stream or behind hipStreamWaitEvent, 10.8 ms when the host waits for the kernels and then
     // queues the copy on an idle stream).  A copier thread waits for frame f's kernels and then issues its D2H; the main
-    // thread waits for the slot's previous D2H before it reuses the slot.  Both block; neither spins.
+    // thread waits for the slot's previous D2H before it reuses the slot.  Both sleep or poll; neither spins.
     Handoff launched;      // frames whose kernels have been queued (e_k recorded)
     Handoff copied;        // frames whose D2H has been queued (e_out recorded)
     std::atomic<int> copy_err{0};
@@ -462,7 +463,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     // Two helpers, so that neither kind of waiting delays the other: the COPIER waits for a band's kernels and queues its D2H
     // on the idle copy stream at once; the FANNER waits for a landed band and copies it out to the caller's buffers.  (One
     // helper doing both fanned band b-1 out only after band b's kernels had finished -- a marker trace showed the first
-    // fan-out starting 8 ms into a 13.9 ms call and the last two sitting in the tail.)  Both block; neither spins.
+    // fan-out starting 8 ms into a 13.9 ms call and the last two sitting in the tail.)  Both sleep or poll; neither spins.
     Handoff landed_q;                       // bands whose D2H has been queued (their "landed" event recorded)
     std::thread copier, fanner;
     const bool threaded = try_thread(copier, [&] {
@@ -734,7 +735,7 @@ int srcnn_y_upscale2x_f32_node_dev(const float* d_in, unsigned w, unsigned h, fl
             if (i + 1 < nsub && (r = launch(i + 1))) return r;
             if ((r = push(i))) return r;
         }
-        // wait for both queues on blocking events (8 workers spinning in hipStreamSynchronize would burn 8 host cores)
+        // wait for both queues by polling their events (8 workers inside hipStreamSynchronize would hold 8 host cores)
         HIP_TRY(hipEventRecord(N.events[nsub], N.st));
         HIP_TRY(hipEventRecord(N.events[nsub + 1], N.copy_st));
         HIP_TRY(wait_event(N.events[nsub]));
