@@ -190,24 +190,34 @@ def process_srcnn_wall(S):
 
 
 def pcie_inclusive(S, frames=16):
-    """Stream of host-resident (page-locked) 4K Y frames: H2D + path + D2H per frame, two slots, hipGraph per slot."""
-    step, free = host_stream_setup(S, frames)
+    """Stream of host-resident (page-locked) 4K Y frames: H2D + path + D2H per frame, two slots; with the per-slot hipGraph
+    replay BASELINE config #5 names, and with plain launches (same kernels, same overlap)."""
     w, h, F = IN_W, IN_H, frames
-    step()                                                       # warm-up + capture
-    ts, cs = [], []
-    for _ in range(3):
-        c0 = time.process_time()
-        t0 = time.perf_counter()
+
+    def variant(use_graph):
+        step, free = host_stream_setup(S, frames, use_graph)
+        step()                                                   # warm-up (+ capture)
         step()
-        ts.append(time.perf_counter() - t0)
-        cs.append(time.process_time() - c0)
-    free()
-    return {"value": round(F * 4 * w * h / 1e6 / min(ts), 1), "unit": "MPix/s", "frames": F, "best_of": 3,
+        ts, cs = [], []
+        for _ in range(3):
+            c0 = time.process_time()
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+            cs.append(time.process_time() - c0)
+        free()
+        return {"MPix/s": round(F * 4 * w * h / 1e6 / min(ts), 1), "wall_s_per_frame": round(min(ts) / F, 6),
+                "host_cpu_s_per_frame": round(min(cs) / F, 6)}
+    eager, graph = variant(0), variant(1)
+    return {"value": graph["MPix/s"], "unit": "MPix/s", "frames": F, "best_of": 3,
             "bytes_per_output_px": {"h2d": 1.0, "d2h": 4.0},
-            "host_cpu_s_per_frame": round(min(cs) / F, 6), "wall_s_per_frame": round(min(ts) / F, 6),
+            "host_cpu_s_per_frame": graph["host_cpu_s_per_frame"], "wall_s_per_frame": graph["wall_s_per_frame"],
+            "plain_launches": eager,
             "note": "planar f32 Y frames in page-locked host memory, H2D + path + D2H overlapped over two slots "
-                    "(srcnn_y_upscale2x_f32_stream, hipGraph per slot); host_cpu_s_per_frame = process CPU time (all "
-                    "threads) per frame: the helper threads sleep or poll, they do not spin; never the headline value"}
+                    "(srcnn_y_upscale2x_f32_stream); `value` = with one hipGraph per slot as BASELINE config #5 asks, "
+                    "`plain_launches` = the same stream without graphs.  host_cpu_s_per_frame = process CPU time (all "
+                    "threads) per frame: the library's threads sleep or poll; with graph replay a thread of the ROCm "
+                    "runtime stays busy from launch to completion (tools/runtime_thread_probe.py).  Never the headline value"}
 
 
 _RESULT_FD = None
@@ -387,7 +397,7 @@ def rccl_probe(S, dist, rank, world, ndev, timeout_s=120.0):
     return int(agreed), None
 
 
-def host_stream_setup(S, frames):
+def host_stream_setup(S, frames, use_graph=1):
     """Page-locked 4K frames for the PCIe-inclusive stream (BASELINE config #5): returns (step, free)."""
     import ctypes as C
     from libsrcnn_amd import synth
@@ -403,7 +413,7 @@ def host_stream_setup(S, frames):
         fr[f] = two[f & 1]
 
     def step():
-        S.check(L.srcnn_y_upscale2x_f32_stream(pin_in, w, h, F, pin_out, 1))
+        S.check(L.srcnn_y_upscale2x_f32_stream(pin_in, w, h, F, pin_out, use_graph))
 
     def free():
         L.srcnn_host_free_pinned(pin_in); L.srcnn_host_free_pinned(pin_out)
@@ -468,10 +478,11 @@ def side_workload(args):
                 "the kernels of k+1) + RCCL gatherv to rank 0" % (w, h, 2 * w, 2 * h, world, tiled.nsub)
     elif args.workload == "host-stream":
         F = max(args.frames, 16)          # one call = one stream of F frames; the first H2D and the last D2H of a call are exposed
-        step, cleanup = host_stream_setup(S, F)
+        step, cleanup = host_stream_setup(S, F, 0 if args.plain_launches else 1)
         mpix_step = world * F * 4 * IN_W * IN_H / 1e6
         label = "stream of %d host-resident (page-locked) 3840x2160 Y frames per rank per step: H2D + path + D2H over two " \
-                "slots, one hipGraph per slot (BASELINE config #5 shape), frames sharded %d-way" % (F, world)
+                "slots, %s (BASELINE config #5 shape), frames sharded %d-way" % (
+                    F, "plain launches" if args.plain_launches else "one hipGraph per slot", world)
         extra["bytes_per_output_px_over_pcie"] = {"h2d": 1.0, "d2h": 4.0}
     elif args.workload == "frames-graph":
         import ctypes as C
@@ -606,6 +617,7 @@ def main():
                          "batch1080p: 64 resident 1920x1080 frames per step; "
                          "frames-graph: the headline workload replayed from one captured hipGraph per step")
     ap.add_argument("--sub-bands", type=int, default=4, help="tiled8k: sub-bands per rank (gather of k overlaps compute of k+1)")
+    ap.add_argument("--plain-launches", action="store_true", help="host-stream: no hipGraph replay (same kernels, same overlap)")
     ap.add_argument("--dry-run", action="store_true", help="launcher/rendezvous plumbing only: no device, value = null")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

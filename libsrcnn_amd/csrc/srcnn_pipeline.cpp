@@ -360,14 +360,19 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if (small) {
             HIP_TRY(hipMemcpyAsync(d_rgb + off, J.rgb + off, nbytes, hipMemcpyHostToDevice, s));
         } else {
-            // on the lane's own input stream, so that the copy runs BESIDE the previous band's kernels; the kernel stream
-            // waits for it device-side (a kernel queue waiting for a copy's event is fine -- it is a copy waiting behind a
-            // kernel queue that does not overlap on this runtime)
+            // on the lane's own input stream, so that the copy runs BESIDE the previous band's kernels.  The band's kernels may
+            // not start before the rows are there: this thread waits for the copy (polling; the previous band keeps the device
+            // busy meanwhile) and only then queues them.  A device-side hipStreamWaitEvent would do the same without the wait,
+            // but on this runtime a cross-stream wait is resolved by a thread of the RUNTIME that stays busy from the call until
+            // the event fires: 9.5 ms of CPU per 11.7 ms call, and no faster (tools/runtime_thread_probe.py,
+            // profiles/r03_wait_cost.txt).  SRCNN_DEVICE_WAIT_IN=1 selects it for A/B runs.
             parallel_memcpy(L.pin_in + (off - src_off), J.rgb + off, nbytes);
             hipEvent_t ev = L.band_events[2 * nb + n_staged++];
             HIP_TRY(hipMemcpyAsync(d_rgb + off, L.pin_in + (off - src_off), nbytes, hipMemcpyHostToDevice, L.in_st));
             HIP_TRY(hipEventRecord(ev, L.in_st));
-            HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+            static const bool device_wait = [] { const char* e = getenv("SRCNN_DEVICE_WAIT_IN"); return e && atoi(e) != 0; }();
+            if (device_wait) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+            else if (wait_event(ev) != hipSuccess) return fail(SRCNN_E_HIP, "stage-in copy");
         }
         if (!fused_shell)
             launch_rgb_split(d_rgb + off, (size_t)(upto - staged) * w, (int)d, sp[0] + (size_t)staged * w, sp[1] + (size_t)staged * w,

@@ -71,9 +71,9 @@ def test_env_srcnn_devices_self_init():
 @pytest.mark.parametrize("env", [{}, {"SRCNN_SHELL_UNFUSED": "1"}, {"SRCNN_RESAMPLE_OLD2D": "1", "SRCNN_SHELL_UNFUSED": "1"},
                                  {"SRCNN_RESAMPLE_2PASS": "1", "SRCNN_SHELL_UNFUSED": "1"}, {"SRCNN_RS_TPB": "1"},
                                  {"SRCNN_MAX_WORKSPACE_MB": "48"}, {"SRCNN_NUMA": "0"}, {"SRCNN_RS_DMA": "0"},
-                                 {"SRCNN_THP": "0", "SRCNN_PREFAULT_THREADS": "3"}, {"SRCNN_PREFAULT": "0"}, {"SRCNN_SPIN_WAIT": "1"}],
+                                 {"SRCNN_THP": "0", "SRCNN_PREFAULT_THREADS": "3"}, {"SRCNN_PREFAULT": "0"}, {"SRCNN_SPIN_WAIT": "1"}, {"SRCNN_DEVICE_WAIT_IN": "1"}],
                          ids=["default", "unfused-shell", "round2-resampler", "two-pass", "tpb1", "small-budget", "no-numa",
-                              "no-dma-resampler", "no-thp-3-prefaulters", "no-prefault", "runtime-waits"])
+                              "no-dma-resampler", "no-thp-3-prefaulters", "no-prefault", "runtime-waits", "device-side-stage-in-wait"])
 def test_processsrcnn_kernel_selections_all_bit_exact(env):
     """The fused colour shell / k_rs2d (default) and every fallback they replace produce the oracle's bytes; so does a
     workspace budget small enough to force many bands inside srcnn_process_u8."""
