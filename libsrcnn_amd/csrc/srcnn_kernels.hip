@@ -1755,7 +1755,11 @@ static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, f
 {
     const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, m_th(NW));
     const int ntiles = tiles_x * tiles_y;
-    const int grid = std::min(ntiles, blocks_per_cu * num_cus);     // resident blocks only; tile loop inside
+    // resident blocks only; tile loop inside.  Fewer tiles than resident blocks (small images, short bands): the kernel deals
+    // such a "last round" out in quarter tiles, so up to four blocks share a tile instead of three quarters of the chip idling
+    const int cap = blocks_per_cu * num_cus;
+    static const bool spread = [] { const char* e = getenv("SRCNN_CONV12_SPREAD"); return !(e && e[0] == '0'); }();   // A/B
+    const int grid = ntiles >= cap ? cap : (spread ? std::min(4 * ntiles, cap) : ntiles);
     const size_t lds = sizeof(float) * m_lds_floats(NW);
     if (strict)
         hipLaunchKernelGGL((k_conv12_mfma<true, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, y_rows,
