@@ -42,4 +42,12 @@ PY
         # the parent never touches the GPU) and prints the one aggregated JSON line
         python3 bench.py --gpus "$N" --steps 5 --warmup 2 --workload $WL --no-extras --no-cpu-baseline
     done
+    echo "== N=$N workload=host-stream, plain launches (no hipGraph replay)" >&2
+    python3 bench.py --gpus "$N" --steps 5 --warmup 2 --workload host-stream --plain-launches --no-extras --no-cpu-baseline
 done
+if [ $DRY -eq 0 ]; then
+    # the single-process model: ONE process drives every visible GPU (contexts + peer copies, no RCCL): ProcessSRCNN over
+    # all devices, the node-tiled frame, the frame stream dealt over the contexts
+    echo "== one process, all devices (tools/node_probe.py --devices all)" >&2
+    python3 tools/node_probe.py --devices all
+fi
