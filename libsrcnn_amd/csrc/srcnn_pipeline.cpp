@@ -239,11 +239,34 @@ struct ProcJob {            // one srcnn_process_u8 call; shared (read-only) by 
 std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, unsigned dh, bool first_share_of_many, int grid, int tile_rows)
 {
     const unsigned cap = budget_band_rows(dw);
-    // a short first band (the GPU starts after a tenth of the input has been staged) and a very short last one (what is left
-    // to copy and fan out after the last kernel)
-    static const double six[] = {0.10, 0.30, 0.30, 0.20, 0.07}, four[] = {0.45, 0.35, 0.15};
-    std::vector<unsigned> cuts = (R1 - R0 >= 512) ? plan_cuts(R0, R1, dw, dh, first_share_of_many ? four : six, first_share_of_many ? 3 : 5, grid, tile_rows)
-                                                  : std::vector<unsigned>{R0, R1};
+    // a short first band (the GPU starts after a twentieth of the input has been staged) and a very short last one (what is
+    // left to copy and fan out after the last kernel).  Measured on 3840x2160 RGB x2, median of 22 calls, same box
+    // (SRCNN_BANDS, tools/process_probe.py): 10/30/30/20/7/3 % 12.5-12.7 ms; 5/15/30/27/16/5/2 % 12.1-12.3 ms; a 3 % first
+    // band or a 7-9 % second-to-last one are slower again (12.4 ms).
+    // Below ~11 Mpx of output (1920x1080 x2: 3.1-3.3 ms either way, 3.3 with seven bands) the per-band costs outweigh the finer
+    // head and tail, and the coarser plan stays.
+    static const double seven[] = {0.05, 0.15, 0.30, 0.27, 0.16, 0.05}, six[] = {0.10, 0.30, 0.30, 0.20, 0.07}, four[] = {0.45, 0.35, 0.15};
+    const bool large = (size_t)(R1 - R0) * dw >= 11000000u;
+    // SRCNN_BANDS="f0,f1,...": band fractions of a lone share for A/B runs (the last band is what is left)
+    static const std::vector<double> env_plan = [] {
+        std::vector<double> v;
+        if (const char* e = getenv("SRCNN_BANDS")) {
+            double sum = 0;
+            for (const char* q = e; *q;) {
+                char* end = nullptr;
+                const double f = strtod(q, &end);
+                if (end == q) break;
+                if (f > 0 && sum + f < 1.0 && v.size() < 15) { v.push_back(f); sum += f; }
+                q = (*end == ',') ? end + 1 : end;
+                if (*end != ',') break;
+            }
+        }
+        return v;
+    }();
+    const bool custom = !env_plan.empty() && !first_share_of_many;
+    const double* plan = custom ? env_plan.data() : (first_share_of_many ? four : (large ? seven : six));
+    const int nplan = custom ? (int)env_plan.size() : (first_share_of_many ? 3 : (large ? 6 : 5));
+    std::vector<unsigned> cuts = (R1 - R0 >= 512) ? plan_cuts(R0, R1, dw, dh, plan, nplan, grid, tile_rows) : std::vector<unsigned>{R0, R1};
     // enforce the budget: split anything larger than `cap` rows
     std::vector<unsigned> out{R0};
     for (size_t i = 1; i < cuts.size(); ++i) {
