@@ -471,10 +471,15 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     unsigned char* pin_rgb = L.pin_out;
     unsigned char* pin_conv = L.pin_out + out_bytes;
     std::atomic<int> copy_err{0};
+    // SRCNN_TRACE stamps, microseconds since entry: first band queued, last band's kernels done, last band landed in staging
+    std::atomic<long> us_first_queued{0}, us_kernels_done{0}, us_landed{0};
+    const auto since = [&] { return (long)std::chrono::duration_cast<std::chrono::microseconds>(now() - t0).count(); };
     Handoff enqueued;                       // bands whose kernels have been queued (their "computed" event recorded)
     auto d2h_band = [&](unsigned b) {
         const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
-        if (wait_event(L.band_events[2 * b]) != hipSuccess ||
+        const hipError_t kd = wait_event(L.band_events[2 * b]);
+        if (b + 1 == nb) us_kernels_done = since();
+        if (kd != hipSuccess ||
             hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
             (J.conv && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess) ||
             hipEventRecord(L.band_events[2 * b + 1], L.copy_st) != hipSuccess) { copy_err = 1; return false; }
@@ -483,6 +488,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     auto fan_band = [&](unsigned b) {
         TraceRange tf("srcnn fan-out band %u", b);
         if (wait_event(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
+        if (b + 1 == nb) us_landed = since();
         const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
         const size_t g0 = (size_t)cuts[b] * dw;
         parallel_memcpy(J.out + g0 * d, pin_rgb + p0 * d, pn * d);
@@ -517,6 +523,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if (!launch_rc) launch_rc = run_band(cuts[b], cuts[b + 1]);
         if (!launch_rc && hipEventRecord(L.band_events[2 * b], s) != hipSuccess) launch_rc = fail(SRCNN_E_HIP, "band %u event record failed", b);
         if (launch_rc) { enqueued.cancel(); break; }
+        if (b == 0) us_first_queued = since();
         if (threaded) enqueued.publish(b + 1);
         else if (d2h_band(b)) fan_band(b);
     }
@@ -534,8 +541,10 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        fprintf(stderr, "srcnn_process_u8 ctx %d (device %d) rows [%u,%u) of %ux%ux%u x%.2f: stage-in %.2f ms, %u bands (compute || D2H || fan-out) %.2f ms%s\n",
-                cx.index, cx.device, R0, R1, w, h, d, (double)dw / w, ms(t0, t1), nb, ms(t1, t2), fused_shell ? ", fused shell" : "");
+        fprintf(stderr, "srcnn_process_u8 ctx %d (device %d) rows [%u,%u) of %ux%ux%u x%.2f: setup %.2f ms, %u bands (compute || D2H || fan-out) %.2f ms%s; "
+                        "since entry: first band queued %.2f, last kernels done %.2f, last band landed %.2f, fanned out %.2f ms\n",
+                cx.index, cx.device, R0, R1, w, h, d, (double)dw / w, ms(t0, t1), nb, ms(t1, t2), fused_shell ? ", fused shell" : "",
+                us_first_queued.load() * 1e-3, us_kernels_done.load() * 1e-3, us_landed.load() * 1e-3, ms(t0, t2));
     }
     return SRCNN_OK;
 }
