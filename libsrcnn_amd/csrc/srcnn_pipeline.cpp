@@ -244,9 +244,12 @@ std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, unsigne
     // (SRCNN_BANDS, tools/process_probe.py): 10/30/30/20/7/3 % 12.5-12.7 ms; 5/15/30/27/16/5/2 % 12.1-12.3 ms; a 3 % first
     // band or a 7-9 % second-to-last one are slower again (12.4 ms).
     // Below ~11 Mpx of output (1920x1080 x2: 3.1-3.3 ms either way, 3.3 with seven bands) the per-band costs outweigh the finer
-    // head and tail, and the coarser plan stays.
+    // head and tail, and the coarser plan stays; below 3 Mpx (only a small share of a multi-context call is banded at all) four
+    // bands.  The plan follows the SHARE's size, lone or not: every context starts its own device after its own first band.
     static const double seven[] = {0.05, 0.15, 0.30, 0.27, 0.16, 0.05}, six[] = {0.10, 0.30, 0.30, 0.20, 0.07}, four[] = {0.45, 0.35, 0.15};
-    const bool large = (size_t)(R1 - R0) * dw >= 11000000u;
+    const size_t share_px = (size_t)(R1 - R0) * dw;
+    const bool large = share_px >= 11000000u;
+    const bool tiny = share_px < 3000000u;       // a small share of a multi-context call (lone images this small are not banded)
     // SRCNN_BANDS="f0,f1,...": band fractions of a lone share for A/B runs (the last band is what is left)
     static const std::vector<double> env_plan = [] {
         std::vector<double> v;
@@ -264,8 +267,8 @@ std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, unsigne
         return v;
     }();
     const bool custom = !env_plan.empty() && !first_share_of_many;
-    const double* plan = custom ? env_plan.data() : (first_share_of_many ? four : (large ? seven : six));
-    const int nplan = custom ? (int)env_plan.size() : (first_share_of_many ? 3 : (large ? 6 : 5));
+    const double* plan = custom ? env_plan.data() : (tiny ? four : (large ? seven : six));
+    const int nplan = custom ? (int)env_plan.size() : (tiny ? 3 : (large ? 6 : 5));
     std::vector<unsigned> cuts = (R1 - R0 >= 512) ? plan_cuts(R0, R1, dw, dh, plan, nplan, grid, tile_rows) : std::vector<unsigned>{R0, R1};
     // enforce the budget: split anything larger than `cap` rows
     std::vector<unsigned> out{R0};

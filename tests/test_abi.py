@@ -165,3 +165,33 @@ def test_process_band_plan_partitions_and_honours_the_workspace_limit(S):
     finally:
         L.srcnn_set_workspace_limit(prev)
     assert L.srcnn_debug_band_plan(10, 10, 100, 0, cuts, 16) < 0
+
+
+def test_process_band_plan_random_ranges(S):
+    """The same invariants over 600 random (row range, width, budget, lone / one-of-many) combinations, incl. the seven-band
+    plan of large lone shares and its SRCNN_BANDS-free defaults: ordered partition, every band within the budget (16-row
+    floor), a first band no larger than a third of a large range (the GPU must start early) and a short last band."""
+    import numpy as np
+    L = S.lib()
+    rng = np.random.default_rng(20261003)
+    cuts = (C.c_uint * 8192)()
+    prev = L.srcnn_set_workspace_limit(16 << 30)
+    try:
+        for _ in range(600):
+            dw = int(rng.integers(1, 16000))
+            r0 = int(rng.integers(0, 5000))
+            r1 = r0 + int(rng.integers(1, 9000))
+            many = int(rng.integers(0, 2))
+            limit = int(rng.choice([16 << 30, 2 << 30, 256 << 20, 8 << 20]))
+            L.srcnn_set_workspace_limit(limit)
+            n = L.srcnn_debug_band_plan(r0, r1, dw, many, cuts, 8192)
+            assert 2 <= n <= 8192, (r0, r1, dw, many, limit, n)
+            c = list(cuts[:n])
+            assert c[0] == r0 and c[-1] == r1 and all(a < b for a, b in zip(c, c[1:])), c
+            cap_rows = max(16, limit // (128 * dw) - 4)
+            assert all(b - a <= cap_rows for a, b in zip(c, c[1:])), (limit, dw, c)
+            if r1 - r0 >= 2048 and dw * (r1 - r0) >= 3000000 and limit == 16 << 30 and dw * (r1 - r0) * 128 < limit:
+                assert c[1] - c[0] <= (r1 - r0) // 3 + 16, c          # early start
+                assert c[-1] - c[-2] <= (r1 - r0) // 4 + 16, c        # short tail
+    finally:
+        L.srcnn_set_workspace_limit(prev)
