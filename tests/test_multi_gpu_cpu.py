@@ -196,3 +196,31 @@ def test_c_band_and_piece_partition_matches_python_and_tiles_the_frame():
                 tot += rounds(a.value, a.value + n.value, out_w, out_h)
         assert tot <= rounds(r0.value, r0.value + rn.value, out_w, out_h) + 1, (r, tot)
     assert L.srcnn_band_rows(10, 3, 3, None, None) != 0 and L.srcnn_tiled_piece(10, 10, 0, 2, 4, 4, None, None) != 0
+
+
+def test_c_pieces_tile_the_frame_for_random_geometries():
+    """400 random (width, height, ranks, pieces): every rank's pieces are consecutive inside its band and all pieces of all ranks
+    cover [0, out_h) exactly once -- the property that lets every rank derive the same gather table without an exchange."""
+    import ctypes as C
+    import libsrcnn_amd as S
+    L = S.lib()
+    rng = np.random.default_rng(7)
+    for _ in range(400):
+        out_h = int(rng.integers(1, 20000)); out_w = int(rng.integers(1, 20000))
+        world = int(rng.integers(1, 17)); nsub = int(rng.integers(1, 17))
+        covered = np.zeros(out_h, np.int32)
+        end_prev = 0
+        for r in range(world):
+            r0, rn = C.c_uint(), C.c_uint()
+            assert L.srcnn_band_rows(out_h, r, world, C.byref(r0), C.byref(rn)) == 0
+            assert r0.value == end_prev                                  # bands are consecutive, in rank order
+            end_prev = r0.value + rn.value
+            pos = r0.value
+            for i in range(nsub):
+                a, n = C.c_uint(), C.c_uint()
+                assert L.srcnn_tiled_piece(out_w, out_h, r, world, i, nsub, C.byref(a), C.byref(n)) == 0
+                assert a.value == pos and a.value + n.value <= r0.value + rn.value, (out_w, out_h, world, nsub, r, i)
+                covered[a.value:a.value + n.value] += 1
+                pos += n.value
+            assert pos == r0.value + rn.value
+        assert end_prev == out_h and (covered == 1).all(), (out_w, out_h, world, nsub)
