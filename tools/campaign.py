@@ -13,7 +13,8 @@ from libsrcnn_amd import synth
 import oracle
 
 def main(n=150, seed=1234):
-    S.init(0)
+    if not os.environ.get("SRCNN_DEVICES"):
+        S.init(0)                                   # SRCNN_DEVICES=0,0,0: the library self-initialises K (virtual) contexts
     o = oracle.Oracle()
     rng = np.random.default_rng(seed)
     bad = 0
@@ -54,7 +55,7 @@ def images(n=60, seed=4321):
     rng = np.random.default_rng(seed)
     bad = 0
     for k in range(n):
-        big = rng.random() < 0.25                                   # above the 8 MB threshold: banded, pipelined, staged
+        big = rng.random() < float(os.environ.get("CAMPAIGN_BIG", 0.25))   # above the 8 MB threshold: banded, pipelined, staged (dealt over the contexts when there are several)
         h = int(rng.integers(600, 1100)) if big else int(rng.integers(1, 200))
         w = int(rng.integers(900, 1500)) if big else int(rng.integers(1, 300))
         d = int(rng.choice([3, 4]))
