@@ -1200,7 +1200,7 @@ static_assert(C3_LH % 4 == 0, "row slots");
 constexpr int C3_BODY = C3_MC * C3_LH / 4;         // body loads per thread per chunk (4 row slots)
 constexpr int C3_HALO = (C3_MC * C3_LH * 4 + 255) / 256;
 
-template <bool STRICT>
+template <bool STRICT, bool OFF64 = false>
 __global__ __launch_bounds__(256) void k_conv3(
     const float* __restrict__ C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows,
     float* __restrict__ out, int out_row0, int out_rows)
@@ -1232,20 +1232,34 @@ __global__ __launch_bounds__(256) void k_conv3(
         gy = clampi(gy, c2_row_base, c2_last);
         return gy - c2_row_base;
     };
+    // Where this thread reads inside a plane never changes during the tile: 32-bit element offsets, computed once.  The loads
+    // are then "uniform plane base (SGPR pair) + per-lane 32-bit offset" -- no 64-bit address arithmetic on the VALU per load
+    // (it was 42 v_lshl_add_u64 per 4-channel chunk, 4 % of the kernel's vector instructions).  OFF64: the launcher's choice for
+    // planes of 4 GiB or more (stage-level calls on caller-provided planes; the Y path bands long before that).
+    using offs_t = std::conditional_t<OFF64, size_t, unsigned>;
+    offs_t boff[C3_LH / 4], hoff[C3_HALO];
+    int hm[C3_HALO];
+#pragma unroll
+    for (int j = 0; j < C3_LH / 4; ++j) boff[j] = ((offs_t)row_of(4 * j + wv) * (offs_t)W + (offs_t)bx) * 4u;     // BYTE offsets
+#pragma unroll
+    for (int i = 0; i < C3_HALO; ++i) {
+        const int rr = min(hrow + 64 * i, C3_MC * C3_LH - 1);
+        hm[i] = rr / C3_LH;
+        hoff[i] = ((offs_t)row_of(rr - hm[i] * C3_LH) * (offs_t)W + (offs_t)hx) * 4u;
+    }
     auto issue = [&](int mc) {                // global -> registers for chunk starting at channel mc
 #pragma unroll
         for (int i = 0; i < C3_BODY; ++i) {
             // staged row rr = 4*i + wv; LH is a multiple of 4, so the channel is i / (LH/4) at compile time
-            const int m = i / (C3_LH / 4), r = 4 * (i % (C3_LH / 4)) + wv;
-            body[i] = C2[(size_t)(mc + m) * plane_stride + (size_t)row_of(r) * W + bx];
+            const int m = i / (C3_LH / 4), j = i % (C3_LH / 4);
+            const char* plane = reinterpret_cast<const char*>(C2 + (size_t)(mc + m) * plane_stride);      // wave-uniform
+            body[i] = *reinterpret_cast<const float*>(plane + boff[j]);
         }
 #pragma unroll
         for (int i = 0; i < C3_HALO; ++i) {
             const int rr = hrow + 64 * i;
-            if (rr < C3_MC * C3_LH) {
-                const int m = rr / C3_LH, r = rr - m * C3_LH;
-                halo[i] = C2[(size_t)(mc + m) * plane_stride + (size_t)row_of(r) * W + hx];
-            }
+            if (rr < C3_MC * C3_LH)
+                halo[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(C2 + ((size_t)mc + hm[i]) * plane_stride) + hoff[i]);
         }
     };
     auto land = [&](float* dst) {             // registers -> LDS
@@ -1807,11 +1821,15 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
         return;
     }
     dim3 grid(cdiv(W, 64), cdiv(out_rows, 16));
-    if (strict)
-        hipLaunchKernelGGL((k_conv3<true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
+    const bool wide = (size_t)c2_rows * (size_t)W * sizeof(float) >= ((size_t)1 << 32);     // per-plane byte offsets beyond 32 bits
+    if (strict && !wide)
+        hipLaunchKernelGGL((k_conv3<true, false>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
+                           out, out_row0, out_rows);
+    else if (strict)
+        hipLaunchKernelGGL((k_conv3<true, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
                            out, out_row0, out_rows);
     else
-        hipLaunchKernelGGL((k_conv3<false>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
+        hipLaunchKernelGGL((k_conv3<false, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
                            out, out_row0, out_rows);
 }
 
