@@ -1821,7 +1821,8 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
         return;
     }
     dim3 grid(cdiv(W, 64), cdiv(out_rows, 16));
-    const bool wide = (size_t)c2_rows * (size_t)W * sizeof(float) >= ((size_t)1 << 32);     // per-plane byte offsets beyond 32 bits
+    static const bool force_wide = [] { const char* e = getenv("SRCNN_CONV3_OFF64"); return e && e[0] == '1'; }();    // test hook
+    const bool wide = force_wide || (size_t)c2_rows * (size_t)W * sizeof(float) >= ((size_t)1 << 32);     // per-plane byte offsets beyond 32 bits
     if (strict && !wide)
         hipLaunchKernelGGL((k_conv3<true, false>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
                            out, out_row0, out_rows);

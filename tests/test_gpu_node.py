@@ -73,9 +73,9 @@ def test_env_srcnn_devices_self_init():
                                  {"SRCNN_MAX_WORKSPACE_MB": "48"}, {"SRCNN_RS_DMA": "0", "SRCNN_NUMA": "0"},
                                  # host-side switches (independent of one another, so they share runs)
                                  {"SRCNN_THP": "0", "SRCNN_PREFAULT_THREADS": "3", "SRCNN_SPIN_WAIT": "1", "SRCNN_DEVICE_WAIT_IN": "1"},
-                                 {"SRCNN_PREFAULT": "0", "SRCNN_BANDS": "0.03,0.07,0.2,0.3,0.3,0.05,0.02", "SRCNN_CONV12_SPREAD": "0"}],
+                                 {"SRCNN_PREFAULT": "0", "SRCNN_BANDS": "0.03,0.07,0.2,0.3,0.3,0.05,0.02", "SRCNN_CONV12_SPREAD": "0", "SRCNN_CONV3_OFF64": "1"}],
                          ids=["default", "unfused-shell", "round2-resampler", "two-pass", "tpb1", "small-budget", "no-dma-resampler-no-numa",
-                              "no-thp-3-prefaulters-runtime-waits-device-stage-in", "no-prefault-eight-bands-no-quarter-spread"])
+                              "no-thp-3-prefaulters-runtime-waits-device-stage-in", "no-prefault-eight-bands-no-quarter-spread-conv3-64bit-offsets"])
 def test_processsrcnn_kernel_selections_all_bit_exact(env):
     """The fused colour shell / k_rs2d (default) and every fallback they replace produce the oracle's bytes; so does a
     workspace budget small enough to force many bands inside srcnn_process_u8."""
