@@ -543,6 +543,31 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
     const int c0 = rs_sload(a.hfirst, x0t), cn = rs_sload(a.hfirst, xl) + rs_sload(a.htaps, xl) - c0;
     const int chunks = (cn + 63) >> 6;
 
+    // this thread's slot of a tile's vertical weight table, fetched one tile ahead like the patch
+    const int wr_r = tid / MAXT, wr_t = tid - wr_r * MAXT;
+    double wreg = 0.0;
+    int freg = 0, nreg = 0;
+    auto fetch = [&](int sub) {
+        const int ry0 = (blockIdx.y * a.tpb + sub) * TH;
+        const int rows = min(TH, a.dst_rows - ry0);
+        const int y0 = a.dst_row0 + ry0, yl = y0 + rows - 1;
+        const int vmin = rs_sload(a.vfirst, y0), nsrc = rs_sload(a.vfirst, yl) + rs_sload(a.vtaps, yl) - vmin;
+        if (tid < TH * MAXT && wr_r < rows) {                  // three independent loads; the tap-count select happens at the use
+            const int y = y0 + wr_r;
+            nreg = a.vtaps[y];
+            freg = a.vfirst[y] - vmin;
+            wreg = a.vwt[(size_t)y * a.vstride + min(wr_t, a.vstride - 1)];
+        }
+        float* raw = raw2 + (sub & 1) * raw_plane;
+        const float* g = a.src_plane + (size_t)vmin * a.src_w + c0 + lane;
+        for (int r = wv; r < nsrc; r += 4)
+            for (int ch = 0; ch < chunks; ++ch)
+                if (ch * 64 + lane < cn) rs_dma_dword(g + (size_t)r * a.src_w + ch * 64, raw + r * LW + ch * 64);
+    };
+
+    fetch(0);              // tile 0's patch is on its way while the horizontal weights below are fetched
+
+
     const double* hp[4][MAXT];
     double w[4][MAXT];
     int nmax = 0;
@@ -566,30 +591,7 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
     // of 7680).  A wave none of whose columns uses the last tap skips it -- that tap would only add +0.0.
     const bool short_taps = MAXT > 1 && __builtin_amdgcn_ballot_w64(nmax > MAXT - 1) == 0;
 
-    // this thread's slot of a tile's vertical weight table, fetched one tile ahead like the patch
-    const int wr_r = tid / MAXT, wr_t = tid - wr_r * MAXT;
-    double wreg = 0.0;
-    int freg = 0, nreg = 0;
-    auto fetch = [&](int sub) {
-        const int ry0 = (blockIdx.y * a.tpb + sub) * TH;
-        const int rows = min(TH, a.dst_rows - ry0);
-        const int y0 = a.dst_row0 + ry0, yl = y0 + rows - 1;
-        const int vmin = rs_sload(a.vfirst, y0), nsrc = rs_sload(a.vfirst, yl) + rs_sload(a.vtaps, yl) - vmin;
-        if (tid < TH * MAXT && wr_r < rows) {                  // three independent loads; the tap-count select happens at the use
-            const int y = y0 + wr_r;
-            nreg = a.vtaps[y];
-            freg = a.vfirst[y] - vmin;
-            wreg = a.vwt[(size_t)y * a.vstride + min(wr_t, a.vstride - 1)];
-        }
-        float* raw = raw2 + (sub & 1) * raw_plane;
-        const float* g = a.src_plane + (size_t)vmin * a.src_w + c0 + lane;
-        for (int r = wv; r < nsrc; r += 4)
-            for (int ch = 0; ch < chunks; ++ch)
-                if (ch * 64 + lane < cn) rs_dma_dword(g + (size_t)r * a.src_w + ch * 64, raw + r * LW + ch * 64);
-    };
-
     const int xa = x0t + 2 * lane, xb = xa + 128;
-    fetch(0);
     for (int sub = 0; sub < a.tpb; ++sub) {
         const int ry0 = (blockIdx.y * a.tpb + sub) * TH;
         if (ry0 >= a.dst_rows) break;
