@@ -794,7 +794,8 @@ constexpr int M_W1 = 81 * 64, M_W2 = 32 * 64, M_B1 = 64, M_B2 = 32;
 constexpr int M_C1 = 32 * 32;                      // per-wave layer-1 slab: 32 channels x 32 px (one MFMA block at a time)
 constexpr int m_th(int nw) { return 2 * nw; }
 constexpr int m_yt(int nw) { return (m_th(nw) + 8) * M_LW; }
-constexpr int m_lds_floats(int nw) { return M_W1 + M_W2 + M_B1 + M_B2 + m_yt(nw) + nw * M_C1; }
+constexpr int m_ybufs(int nw) { return nw == 8 ? 2 : 1; }      // the production geometry double-buffers the Y tile (LDS-DMA prefetch)
+constexpr int m_lds_floats(int nw) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(nw) * m_yt(nw) + nw * M_C1; }
 
 // One tap-step of the product/accumulate pipeline.  PIPE=1: the MFMA of step t+1 is issued, then the VALU
 // folds in the result of step t (two result buffers).  PIPE=0: one buffer, the adds wait for their own
@@ -810,23 +811,49 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
     float* W2s = W1s + M_W1;             // [f/2][lane]: lanes 0-31 -> w2[m=lane][f], 32-63 -> w2[m=lane-32][f+1]
     float* B1s = W2s + M_W2;             // [half][reg] layer-1 bias in accumulator layout
     float* B2s = B1s + M_B1;             // [half][reg] layer-2 bias in accumulator layout
-    float* Yt  = B2s + M_B2;
-    float* C1s = Yt + YT;
+    float* Yt  = B2s + M_B2;             // [m_ybufs][YT]
+    float* C1s = Yt + m_ybufs(NW) * YT;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
 
-    for (int e = tid; e < M_W1; e += NT) W1s[e] = (&cW.w1t[0][0])[e];
-    for (int e = tid; e < M_W2; e += NT) {
-        const int fp = e >> 6, l = e & 63;
-        W2s[e] = cW.w2[l & 31][2 * fp + (l >> 5)];
-    }
-    if (tid < 64) {
-        const int hf = tid >> 5, r = tid & 31;
-        B1s[tid] = cW.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
-    }
-    if (tid < 32) {
-        const int hf = tid >> 4, r = tid & 15;
-        B2s[tid] = cW.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
+    // The block's weight image (29 KB, MFMA operand order).  With the production geometry it is moved by LDS-DMA as well: all
+    // 15 pieces per thread are in flight at once and land before the first tile's barrier; the load -> wait -> ds_write loops
+    // cost ten global-memory latencies per launch, which a band of a ProcessSRCNN call or a small image cannot amortise.
+    constexpr bool WDMA = m_ybufs(NW) == 2;
+    const int wave_e0w = __builtin_amdgcn_readfirstlane(tid & ~63);
+    if constexpr (WDMA) {
+#pragma unroll
+        for (int i = 0; i < (M_W1 + NT - 1) / NT; ++i) {
+            const int e = tid + i * NT;
+            if (e < M_W1) rs_dma_dword(&cW.w1t[0][0] + e, W1s + i * NT + wave_e0w);
+        }
+#pragma unroll
+        for (int i = 0; i < (M_W2 + NT - 1) / NT; ++i) {
+            const int e = tid + i * NT;
+            if (e < M_W2) { const int fp = e >> 6, l = e & 63; rs_dma_dword(&cW.w2[l & 31][2 * fp + (l >> 5)], W2s + i * NT + wave_e0w); }
+        }
+        if (tid < 64) {
+            const int hf = tid >> 5, r = tid & 31;
+            rs_dma_dword(&cW.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)], B1s);
+        }
+        if (tid < 32) {
+            const int hf = tid >> 4, r = tid & 15;
+            rs_dma_dword(&cW.b2[8 * (r >> 2) + 4 * hf + (r & 3)], B2s);
+        }
+    } else {
+        for (int e = tid; e < M_W1; e += NT) W1s[e] = (&cW.w1t[0][0])[e];
+        for (int e = tid; e < M_W2; e += NT) {
+            const int fp = e >> 6, l = e & 63;
+            W2s[e] = cW.w2[l & 31][2 * fp + (l >> 5)];
+        }
+        if (tid < 64) {
+            const int hf = tid >> 5, r = tid & 31;
+            B1s[tid] = cW.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
+        }
+        if (tid < 32) {
+            const int hf = tid >> 4, r = tid & 15;
+            B2s[tid] = cW.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
+        }
     }
     float* myC1 = C1s + wv * M_C1;
     const f32x32 zero32 = {};
@@ -837,24 +864,62 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
     // on 512 workgroups instead of leaving 368 of them idle for a whole one (-0.8 % of the launch).
     const int full = (ntiles / (int)gridDim.x) * (int)gridDim.x;
     const int nitems = full + 4 * (ntiles - full);
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        int tile = item, s0 = 0, s1 = 4;
+    // The Y tile (+4 halo) of the NEXT item is on its way while the current one is computed: LDS-DMA (global_load_lds_dword, no
+    // VGPR destination -- the kernel has none to spare) into the other of two tile buffers; element e of a tile goes to
+    // Yt[e], and consecutive lanes take consecutive e, which is exactly the DMA's "wave base + lane * 4" destination.  The
+    // staging used to be a load -> wait -> ds_write loop between two barriers: NPRE global-memory latencies per tile with all
+    // of the workgroup's waves standing still, and two barriers per tile instead of one.
+    constexpr bool DMA = m_ybufs(NW) == 2;
+    constexpr int NPRE = (YT + NT - 1) / NT;
+    auto tile_of = [&](int item, int& s0, int& s1) {
+        int tile = item; s0 = 0; s1 = 4;
         if (item >= full) { const int i = item - full; tile = full + (i >> 2); s0 = i & 3; s1 = s0 + 1; }
+        return tile;
+    };
+    const int wave_e0 = wave_e0w;         // first element of this wave's 64 (an SGPR: the DMA's LDS base must be uniform)
+    auto request = [&](int item, float* buf) {
+        int q0, q1;
+        const int tile = tile_of(item, q0, q1);
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
         const int tx0 = txi * M_TW, ty0 = out_row0 + tyi * TH;
-        __syncthreads();
-        for (int e = tid; e < YT; e += NT) {
-            const int r = e / M_LW, c = e - r * M_LW;
-            const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
-            Yt[e] = Y[(size_t)(gy - y_row_base) * W + gx];
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int e = tid + i * NT;
+            if (e < YT) {
+                const int r = e / M_LW, c = e - r * M_LW;
+                const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
+                rs_dma_dword(Y + (size_t)(gy - y_row_base) * W + gx, buf + i * NT + wave_e0);
+            }
         }
-        __syncthreads();
+    };
+    int it = 0;
+    if constexpr (DMA) { if ((int)blockIdx.x < nitems) request(blockIdx.x, Yt); }
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++it) {
+        int s0, s1;
+        const int tile = tile_of(item, s0, s1);
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * M_TW, ty0 = out_row0 + tyi * TH;
+        const float* Ytc = Yt;
+        if constexpr (DMA) {
+            Ytc = Yt + (it & 1) * YT;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the item's tile has landed
+            __syncthreads();                                    // ... everybody's has; the previous item is finished everywhere
+            if (item + (int)gridDim.x < nitems) request(item + gridDim.x, Yt + ((it + 1) & 1) * YT);
+        } else {
+            __syncthreads();
+            for (int e = tid; e < YT; e += NT) {
+                const int r = e / M_LW, c = e - r * M_LW;
+                const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
+                Yt[e] = Y[(size_t)(gy - y_row_base) * W + gx];
+            }
+            __syncthreads();
+        }
 
 #pragma unroll 1
         for (int s = s0; s < s1; ++s) {
             const int sg = wv * 4 + s;
             const int trow = sg >> 1, seg = sg & 1;
-            const float* yrow = Yt + trow * M_LW + seg * 32 + col;
+            const float* yrow = Ytc + trow * M_LW + seg * 32 + col;
 
             // ---- layer 1: 81 taps, one MFMA (products) + 16 packed adds each ----
             // Pinned with sched_barrier + PIN: left alone, the scheduler hoists all 81 independent MFMAs and
