@@ -126,6 +126,8 @@ void build_dev_weights(DevWeights& d)
         for (int f = 0; f < 64; ++f) d.w2[m][f] = w2[m * 64 + f];
         for (int dy = 0; dy < 5; ++dy)
             for (int dx = 0; dx < 5; ++dx) d.w3[m][dy * 5 + dx] = w3[m * 25 + dx * 5 + dy];
+        for (int dy = 0; dy < 5; ++dy)
+            for (int dx = 0; dx < 6; ++dx) d.w3p[m * 30 + dy * 6 + dx] = dx < 5 ? d.w3[m][dy * 5 + dx] : 0.f;
     }
     d.b3 = *b3;
 }

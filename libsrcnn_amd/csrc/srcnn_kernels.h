@@ -20,6 +20,7 @@ struct DevWeights {
     float w3[C2N][25];
     float b3;
     float pad_[3];
+    float w3p[C2N * 30];           // w3 in k_conv3's packed-operand order: [m][dy][(w0,w1) (w2,w3) w4 pad]
 };
 
 struct DevAxisTable {          // device pointers into one uploaded AxisTable

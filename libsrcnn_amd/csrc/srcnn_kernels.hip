@@ -1280,9 +1280,13 @@ __global__ __launch_bounds__(256) void k_conv3(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c2_last = c2_row_base + c2_rows - 1;
     if constexpr (STRICT) {
-        for (int e = tid; e < C2N * 30; e += 256) {
-            const int m = e / 30, k = e - m * 30, dy = k / 6, dx = k - dy * 6;
-            w3s[e] = dx < 5 ? cW.w3[m][dy * 5 + dx] : 0.f;
+        // the packed weight image exists in constant memory as such (filled on the host): four LDS-DMA pieces per thread, all in
+        // flight at once -- every one of the 32 400 workgroups of an 8K frame pays this prologue
+        const int wave_e0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+#pragma unroll
+        for (int i = 0; i < (C2N * 30 + 255) / 256; ++i) {
+            const int e = tid + i * 256;
+            if (e < C2N * 30) rs_dma_dword(cW.w3p + e, w3s + i * 256 + wave_e0);
         }
     }
 
@@ -1343,6 +1347,7 @@ __global__ __launch_bounds__(256) void k_conv3(
 
     issue(0);
     land(tile[0]);
+    if constexpr (STRICT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight image's DMA
     __syncthreads();
 
 #pragma unroll 1
