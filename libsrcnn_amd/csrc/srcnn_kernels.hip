@@ -794,13 +794,15 @@ constexpr int M_W1 = 81 * 64, M_W2 = 32 * 64, M_B1 = 64, M_B2 = 32;
 constexpr int M_C1 = 32 * 32;                      // per-wave layer-1 slab: 32 channels x 32 px (one MFMA block at a time)
 constexpr int m_th(int nw) { return 2 * nw; }
 constexpr int m_yt(int nw) { return (m_th(nw) + 8) * M_LW; }
-constexpr int m_ybufs(int nw) { return nw == 8 ? 2 : 1; }      // the production geometry double-buffers the Y tile (LDS-DMA prefetch)
-constexpr int m_lds_floats(int nw) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(nw) * m_yt(nw) + nw * M_C1; }
+constexpr int m_ybufs(bool ld) { return ld ? 2 : 1; }          // LDS-DMA staging double-buffers the Y tile
+constexpr int m_lds_floats(int nw, bool ld) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(ld) * m_yt(nw) + nw * M_C1; }
 
 // One tap-step of the product/accumulate pipeline.  PIPE=1: the MFMA of step t+1 is issued, then the VALU
 // folds in the result of step t (two result buffers).  PIPE=0: one buffer, the adds wait for their own
 // MFMA and other waves fill the gap (fewer registers -> more waves per SIMD).
-template <bool STRICT, int NW, int PIPE, int WPS>
+// LD: weights and Y tiles staged by LDS-DMA (the production form, variant 1); variant 4 is the same geometry with the
+// load -> wait -> ds_write staging it replaced (SRCNN_CONV12_VARIANT=4: A/B runs, and a fallback should the DMA path ever be suspected).
+template <bool STRICT, int NW, int PIPE, int WPS, bool LD = false>
 __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
     const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
@@ -812,14 +814,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
     float* B1s = W2s + M_W2;             // [half][reg] layer-1 bias in accumulator layout
     float* B2s = B1s + M_B1;             // [half][reg] layer-2 bias in accumulator layout
     float* Yt  = B2s + M_B2;             // [m_ybufs][YT]
-    float* C1s = Yt + m_ybufs(NW) * YT;
+    float* C1s = Yt + m_ybufs(LD) * YT;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
 
     // The block's weight image (29 KB, MFMA operand order).  With the production geometry it is moved by LDS-DMA as well: all
     // 15 pieces per thread are in flight at once and land before the first tile's barrier; the load -> wait -> ds_write loops
     // cost ten global-memory latencies per launch, which a band of a ProcessSRCNN call or a small image cannot amortise.
-    constexpr bool WDMA = m_ybufs(NW) == 2;
+    constexpr bool WDMA = LD;
     const int wave_e0w = __builtin_amdgcn_readfirstlane(tid & ~63);
     if constexpr (WDMA) {
 #pragma unroll
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
     // Yt[e], and consecutive lanes take consecutive e, which is exactly the DMA's "wave base + lane * 4" destination.  The
     // staging used to be a load -> wait -> ds_write loop between two barriers: NPRE global-memory latencies per tile with all
     // of the workgroup's waves standing still, and two barriers per tile instead of one.
-    constexpr bool DMA = m_ybufs(NW) == 2;
+    constexpr bool DMA = LD;
     constexpr int NPRE = (YT + NT - 1) / NT;
     auto tile_of = [&](int item, int& s0, int& s1) {
         int tile = item; s0 = 0; s1 = 4;
@@ -1270,7 +1272,7 @@ constexpr int C3_HALO = (C3_MC * C3_LH * 4 + 255) / 256;
 template <bool STRICT, bool OFF64 = false>
 __global__ __launch_bounds__(256) void k_conv3(
     const float* __restrict__ C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows,
-    float* __restrict__ out, int out_row0, int out_rows)
+    float* __restrict__ out, int out_row0, int out_rows, int weights_by_dma)
 {
     __shared__ float tile[2][C3_MC * C3_CH];
     __shared__ __attribute__((aligned(16))) float w3s[C2N * 30];   // [m][dy][6]: (w0,w1) (w2,w3) w4 pad -- packed-operand order
@@ -1283,10 +1285,14 @@ __global__ __launch_bounds__(256) void k_conv3(
         // the packed weight image exists in constant memory as such (filled on the host): four LDS-DMA pieces per thread, all in
         // flight at once -- every one of the 32 400 workgroups of an 8K frame pays this prologue
         const int wave_e0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+        if (weights_by_dma) {
 #pragma unroll
-        for (int i = 0; i < (C2N * 30 + 255) / 256; ++i) {
-            const int e = tid + i * 256;
-            if (e < C2N * 30) rs_dma_dword(cW.w3p + e, w3s + i * 256 + wave_e0);
+            for (int i = 0; i < (C2N * 30 + 255) / 256; ++i) {
+                const int e = tid + i * 256;
+                if (e < C2N * 30) rs_dma_dword(cW.w3p + e, w3s + i * 256 + wave_e0);
+            }
+        } else {                                               // SRCNN_CONV3_WDMA=0 (A/B runs, fallback)
+            for (int e = tid; e < C2N * 30; e += 256) w3s[e] = cW.w3p[e];
         }
     }
 
@@ -1800,20 +1806,20 @@ void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, flo
 // by 2-5 % on MI355X):
 //   0: 256 threads, pipelined (two result buffers), 3 waves/SIMD      1: 512 threads, single buffer, 4 waves/SIMD
 //   2: 256 threads, single buffer, 3 waves/SIMD                        3: 512 threads, pipelined, 2 waves/SIMD
-template <bool STRICT, int NW, int PIPE, int WPS>
+template <bool STRICT, int NW, int PIPE, int WPS, bool LD>
 static hipError_t prep_one()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<STRICT, NW, PIPE, WPS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * m_lds_floats(NW)));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<STRICT, NW, PIPE, WPS, LD>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * m_lds_floats(NW, LD)));
 }
 
 hipError_t conv12_mfma_prepare()
 {
     hipError_t e;
-#define PREP(NW, PIPE, WPS)                                        \
-    if ((e = prep_one<true, NW, PIPE, WPS>()) != hipSuccess) return e; \
-    if ((e = prep_one<false, NW, PIPE, WPS>()) != hipSuccess) return e;
-    PREP(4, 1, 3) PREP(8, 0, 4) PREP(4, 0, 3) PREP(8, 1, 2)
+#define PREP(NW, PIPE, WPS, LD)                                        \
+    if ((e = prep_one<true, NW, PIPE, WPS, LD>()) != hipSuccess) return e; \
+    if ((e = prep_one<false, NW, PIPE, WPS, LD>()) != hipSuccess) return e;
+    PREP(4, 1, 3, false) PREP(8, 0, 4, true) PREP(4, 0, 3, false) PREP(8, 1, 2, false) PREP(8, 0, 4, false)
 #undef PREP
     return hipSuccess;
 }
@@ -1835,7 +1841,7 @@ void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows,
                        out_row0, out_rows, tiles_x, ntiles);
 }
 
-template <int NW, int PIPE, int WPS>
+template <int NW, int PIPE, int WPS, bool LD>
 static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                      int out_rows, bool strict, int num_cus, int blocks_per_cu, hipStream_t s)
 {
@@ -1846,12 +1852,12 @@ static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, f
     const int cap = blocks_per_cu * num_cus;
     static const bool spread = [] { const char* e = getenv("SRCNN_CONV12_SPREAD"); return !(e && e[0] == '0'); }();   // A/B
     const int grid = ntiles >= cap ? cap : (spread ? std::min(4 * ntiles, cap) : ntiles);
-    const size_t lds = sizeof(float) * m_lds_floats(NW);
+    const size_t lds = sizeof(float) * m_lds_floats(NW, LD);
     if (strict)
-        hipLaunchKernelGGL((k_conv12_mfma<true, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, y_rows,
+        hipLaunchKernelGGL((k_conv12_mfma<true, NW, PIPE, WPS, LD>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, y_rows,
                            C2, plane_stride, out_row0, out_rows, tiles_x, ntiles);
     else
-        hipLaunchKernelGGL((k_conv12_mfma<false, NW, PIPE, WPS>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, y_rows,
+        hipLaunchKernelGGL((k_conv12_mfma<false, NW, PIPE, WPS, LD>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, y_rows,
                            C2, plane_stride, out_row0, out_rows, tiles_x, ntiles);
 }
 
@@ -1875,10 +1881,11 @@ void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows
 {
     if (out_rows <= 0) return;
     switch (variant) {
-    case 0: launch_v<4, 1, 3>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
-    default: launch_v<8, 0, 4>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 2, s); break;
-    case 2: launch_v<4, 0, 3>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
-    case 3: launch_v<8, 1, 2>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 1, s); break;
+    case 0: launch_v<4, 1, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
+    default: launch_v<8, 0, 4, true>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 2, s); break;
+    case 2: launch_v<4, 0, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 3, s); break;
+    case 3: launch_v<8, 1, 2, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 1, s); break;
+    case 4: launch_v<8, 0, 4, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, strict, num_cus, 2, s); break;
     }
 }
 
@@ -1894,16 +1901,17 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
     }
     dim3 grid(cdiv(W, 64), cdiv(out_rows, 16));
     static const bool force_wide = [] { const char* e = getenv("SRCNN_CONV3_OFF64"); return e && e[0] == '1'; }();    // test hook
+    static const int wdma = [] { const char* e = getenv("SRCNN_CONV3_WDMA"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool wide = force_wide || (size_t)c2_rows * (size_t)W * sizeof(float) >= ((size_t)1 << 32);     // per-plane byte offsets beyond 32 bits
     if (strict && !wide)
         hipLaunchKernelGGL((k_conv3<true, false>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
-                           out, out_row0, out_rows);
+                           out, out_row0, out_rows, wdma);
     else if (strict)
         hipLaunchKernelGGL((k_conv3<true, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
-                           out, out_row0, out_rows);
+                           out, out_row0, out_rows, wdma);
     else
         hipLaunchKernelGGL((k_conv3<false, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
-                           out, out_row0, out_rows);
+                           out, out_row0, out_rows, wdma);
 }
 
 void launch_conv1_planes(const float* Y, int W, int H, float* C1, hipStream_t s)

@@ -261,7 +261,7 @@ def test_host_stream_equals_singles(srcnn, use_graph):
 
 
 @pytest.mark.parametrize("env", [{"SRCNN_CONV12_VARIANT": "0"}, {"SRCNN_CONV12_VARIANT": "2"}, {"SRCNN_CONV12_VARIANT": "3"},
-                                 {"SRCNN_CONV12": "valu"}])
+                                 {"SRCNN_CONV12_VARIANT": "4", "SRCNN_CONV3_WDMA": "0"}, {"SRCNN_CONV12": "valu"}])
 def test_alternate_layer12_kernels_bit_exact(env, golden, tmp_path):
     """The A/B variants of the layer-1+2 kernel (selected by environment at init, hence a subprocess) all
     reproduce the golden output bit for bit."""
