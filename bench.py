@@ -330,6 +330,15 @@ def reduce_max(dist, x):
     return float(t[0])
 
 
+def gather_per_rank(dist, world, x):
+    """Every rank's own figure, in rank order (so a straggler shows): a list on every rank."""
+    if dist is None or world == 1:
+        return [round(float(x), 4)]
+    box = [None] * world
+    dist.all_gather_object(box, round(float(x), 4))
+    return box
+
+
 def reduce_min(dist, x):
     return -reduce_max(dist, -x)
 
@@ -513,18 +522,28 @@ def side_workload(args):
 
     comm_made = args.workload == "tiled8k"
 
+    def drain():
+        # the tiled frame queues RCCL work: wait for it with the library's bounded wait (a missing peer or a mismatched gather
+        # table ends in SRCNN_E_COMM after SRCNN_COMM_TIMEOUT_MS instead of hanging the job)
+        if args.workload == "tiled8k":
+            S.check(L.srcnn_comm_wait(None))
+        S.sync()
+
     for _ in range(args.warmup):
         step()
-    S.sync(); barrier()
+    drain(); barrier()
     cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    S.sync(); barrier()
+    drain()
+    t_own = time.perf_counter()
+    barrier()
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
     cpu_s = (time.process_time() - cpu0) / args.steps
     ms = reduce_max(dist, ms)
     cpu_s = reduce_max(dist, cpu_s)
+    extra["per_rank_ms_per_step"] = gather_per_rank(dist, world, (t_own - t0) * 1e3 / args.steps)
     if verify is not None:
         extra["verify"] = verify()
     if args.workload != "tiled8k" and world > 1:      # after the measurement, like the headline workload
@@ -678,12 +697,14 @@ def main():
     for _ in range(args.steps):
         step()
     S.sync()
+    t_own = time.perf_counter()          # this rank's own finish, before the barrier: reported per rank, never the headline
     barrier()
     t1 = time.perf_counter()
     S.profile_enable(False)
     prof = S.profile_read()
 
     ms_per_step = reduce_max(dist, (t1 - t0) * 1e3 / args.steps)
+    per_rank_ms = gather_per_rank(dist, world, (t_own - t0) * 1e3 / args.steps)
 
     # N > 1: prove, outside the timed region, that RCCL connects all N ranks (one communicator + one barrier); the
     # headline data path itself has no collective.  AFTER the measurement: a fabric that wedges half-way can leave
@@ -706,6 +727,7 @@ def main():
             "metric": METRIC,
             "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "stream of synthetic 3840x2160 Y frames -> 7680x4320 (2x), %d frames/GPU/step, frames "

@@ -35,8 +35,9 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define SRCNN_AMD_ABI_VERSION 3   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts
-                                   * 3: contexts (srcnn_init_devices ...), node-level calls, srcnn_trim, sub-band gather */
+#define SRCNN_AMD_ABI_VERSION 4   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts
+                                   * 3: contexts (srcnn_init_devices ...), node-level calls, srcnn_trim, sub-band gather
+                                   * 4: SRCNN_MODE_RELAXED / srcnn_set_relaxation, srcnn_process_u8_begin/_wait, srcnn_comm_wait / srcnn_comm_set_timeout_ms */
 
 /* error codes.  -1/-2/-11/-12/-100 are the reference's own (src/libsrcnn.cpp:951-966,883,910,636) */
 #define SRCNN_OK            0
@@ -62,6 +63,15 @@ extern "C" {
 #define SRCNN_MODE_FAST     1   /* fp32 FMA chains (layers 1+2 on the fp32 MFMA, layer 3 v_fma_f32) */
 #define SRCNN_MODE_FAST_F16 2   /* layers 1+2 as split-fp16 GEMMs on the fp16 matrix pipe (3 MFMAs per product
                                  * term set, fp32 accumulate); same error class as SRCNN_MODE_FAST */
+#define SRCNN_MODE_RELAXED  3   /* the strict kernels with the roundings named by srcnn_set_relaxation() given up, layer by
+                                 * layer: the instrument behind the per-layer error matrix (profiles/r04_error_matrix.txt).
+                                 * NOT a parity tier: every single relaxation measures above the 1e-4 bar */
+/* relaxation bits (src/libsrcnn.cpp:395-410 layer 1, :433-437 layer 2, :500-517 layer 3) */
+#define SRCNN_RELAX_L1      1u  /* layer 1: acc = fma(w, y, acc) per tap (fp32 MFMA, C = acc) instead of product then add */
+#define SRCNN_RELAX_L2      2u  /* layer 2: likewise over the 64 channels */
+#define SRCNN_RELAX_L3_X64  4u  /* layer 3: exact products (v_fma_f64 on widened operands) instead of fp32-rounded ones;
+                                 * per-channel fp64 sums and the fp32 running sum as the reference's */
+#define SRCNN_RELAX_L3_F32  8u  /* layer 3: fp32 FMA chain per channel */
 
 /* ---- lifecycle (the reference has none: it is stateless CPU code; src/libsrcnn.cpp:91-92 are its
  *      only globals).  srcnn_init is idempotent and thread-safe; every compute call self-inits on
@@ -102,6 +112,8 @@ int         srcnn_trim(void);                      /* give back what idle lanes 
 const char* srcnn_last_error(void);
 int         srcnn_set_mode(int mode);              /* SRCNN_MODE_*; returns previous mode or <0 */
 int         srcnn_get_mode(void);
+int         srcnn_set_relaxation(unsigned mask);   /* SRCNN_RELAX_* bits used by SRCNN_MODE_RELAXED (default L3_X64);
+                                                    * returns the previous mask or <0.  Takes effect for calls that start later */
 int         srcnn_device_name(char* buf, size_t cap);
 /* Upper bound, in bytes, on the layer-2 scratch (128 B per output pixel) one pass may hold; larger frames / bands
  * are produced in horizontal sub-bands with identical results.  Default 16 GiB or env SRCNN_MAX_WORKSPACE_MB.
@@ -190,7 +202,8 @@ int srcnn_y_path_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw,
 #define SRCNN_STAGE_COUNT    3
 int srcnn_profile_enable(int on);                       /* returns previous setting */
 int srcnn_profile_reset(void);
-int srcnn_profile_read(int stage, double* total_ms, unsigned long long* launches);
+int srcnn_profile_read(int stage, double* total_ms, unsigned long long* launches);   /* summed over the contexts */
+int srcnn_profile_read_context(int context, int stage, double* total_ms, unsigned long long* launches);   /* one context */
 
 /* ---- stage-level entry points (layer parity tests, debugging; each is one reference function) ---- */
 /* FRAWResizeEngine::scale (src/frawscale.cpp:162-286) */
@@ -226,6 +239,15 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
 int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply,
                      int filter, unsigned char* out, unsigned char* conv_opt);
 
+/* The same call, asynchronous.  begin() validates nothing but `job`, starts the work and returns at once; wait() blocks until
+ * the image is complete, returns what srcnn_process_u8 would have returned (its text in srcnn_last_error()) and frees the
+ * job.  rgb / out / conv_opt must stay valid and untouched in between; every begin() needs exactly one wait().  A caller that
+ * upscales a sequence keeps two jobs in flight, so that the device never idles between images (the harness of the reference
+ * times one blocking call, src/test.cpp:653-672; this is for callers with more than one image). */
+int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply,
+                           int filter, unsigned char* out, unsigned char* conv_opt, void** job);
+int srcnn_process_u8_wait(void* job);
+
 /* Output geometry of ProcessSRCNN for (w,h,multiply) with or without step scaling: the reference only
  * returns a byte count (outbuffsz) and truncates w*m pass by pass (src/libsrcnn.cpp:662-663, 980-1061). */
 int srcnn_output_size(unsigned w, unsigned h, float multiply, int stepscale, unsigned* out_w, unsigned* out_h);
@@ -246,6 +268,13 @@ int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, un
 /* Test hook: number of contribution tables currently cached (bounded, only unreferenced tables are evicted) and
  * of ProcessSRCNN lanes created so far (at most 4 per context), both summed over the contexts. */
 int srcnn_debug_counts(int* tables, int* lanes);
+
+/* Diagnostic: the shader clock of every layer-1+2 launch.  While on, each launch records the shader-cycle and 100 MHz counters
+ * over the lifetime of its first workgroup (cycles / ticks x 100 = MHz; ticks / 100 = microseconds).  probe(on) resets the
+ * record and returns the previous setting; read() synchronises the device, returns the number of launches recorded on
+ * `context` (at most 8192 are kept) and writes up to `cap` of them in launch order. */
+int srcnn_debug_clock_probe(int on);
+int srcnn_debug_clock_read(int context, unsigned long long* cycles, unsigned long long* ticks, int cap);
 
 /* Test hook (no device needed): the band cut points srcnn_process_u8 uses for output rows [r0, r1) of a dw-wide image under
  * the current workspace limit; returns their number (first = r0, last = r1), writes at most `cap` of them. */
@@ -289,6 +318,15 @@ int srcnn_band_rows(unsigned out_h, int rank, int nranks, unsigned* row0, unsign
 int srcnn_tiled_piece(unsigned out_w, unsigned out_h, int rank, int nranks, int piece, int npieces, unsigned* row0, unsigned* rows);
 int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, void* stream);
 int srcnn_comm_barrier(void* stream);
+/* No wait on a peer is unbounded.  Every RCCL call that can block on the host runs under a deadline, and the host waits for
+ * queued communication with srcnn_comm_wait (a bounded srcnn_stream_sync; srcnn_comm_barrier uses it).  When the deadline
+ * passes -- a rank died, or the ranks derived different gather tables -- the communicator is aborted (ncclCommAbort), the
+ * call returns SRCNN_E_COMM, and every later srcnn_comm_* call fails at once until srcnn_comm_destroy + srcnn_comm_init.
+ * Default 60000 ms, env SRCNN_COMM_TIMEOUT_MS; 0 = no deadline.  srcnn_comm_set_timeout_ms returns the previous value.
+ * SRCNN_COMM_CHECK=1 additionally all-reduces a checksum of every new counts / offsets table before the first gather that
+ * uses it, so that ranks which disagree return SRCNN_E_COMM together instead of pairing a send with the wrong receive. */
+int srcnn_comm_wait(void* stream);
+int srcnn_comm_set_timeout_ms(int ms);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -17,30 +17,32 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsrcnn_amd.so")
 
 SRCNNF_Nearest, SRCNNF_Bilinear, SRCNNF_Bicubic, SRCNNF_Lanczos3, SRCNNF_Bspline = range(5)
-MODE_STRICT, MODE_FAST, MODE_FAST_F16 = 0, 1, 2
+MODE_STRICT, MODE_FAST, MODE_FAST_F16, MODE_RELAXED = 0, 1, 2, 3
+RELAX_L1, RELAX_L2, RELAX_L3_X64, RELAX_L3_F32 = 1, 2, 4, 8
 
 # every symbol include/srcnn_amd.h declares (checked by tests/test_abi.py)
 C_ABI_SYMBOLS = [
     "srcnn_abi_version", "srcnn_device_count", "srcnn_init", "srcnn_init_devices", "srcnn_context_count",
     "srcnn_context_device", "srcnn_set_context", "srcnn_get_context", "srcnn_shutdown", "srcnn_trim", "srcnn_last_error",
-    "srcnn_set_mode", "srcnn_get_mode", "srcnn_device_name", "srcnn_set_workspace_limit",
+    "srcnn_set_mode", "srcnn_get_mode", "srcnn_set_relaxation", "srcnn_device_name", "srcnn_set_workspace_limit",
     "srcnn_dev_alloc", "srcnn_dev_free", "srcnn_host_alloc_pinned", "srcnn_host_free_pinned",
     "srcnn_memcpy_h2d", "srcnn_memcpy_d2h", "srcnn_memset_dev", "srcnn_stream_create", "srcnn_stream_destroy",
     "srcnn_stream_sync", "srcnn_device_sync", "srcnn_event_create", "srcnn_event_destroy", "srcnn_event_record",
     "srcnn_stream_wait_event",
     "srcnn_event_elapsed_ms",
-    "srcnn_profile_enable", "srcnn_profile_reset", "srcnn_profile_read",
+    "srcnn_profile_enable", "srcnn_profile_reset", "srcnn_profile_read", "srcnn_profile_read_context",
     "srcnn_y_upscale2x_f32_dev", "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev",
     "srcnn_y_upscale2x_f32_node_dev",
     "srcnn_batch_graph_create", "srcnn_batch_graph_launch", "srcnn_batch_graph_destroy",
     "srcnn_y_path_f32_dev", "srcnn_resample_f32_dev", "srcnn_conv1_f32_dev", "srcnn_conv2_f32_dev",
     "srcnn_conv3_f32_dev", "srcnn_conv12_f32_dev",
     "srcnn_y_upscale2x_f32", "srcnn_y_upscale2x_f32_batch", "srcnn_y_upscale2x_f32_stream", "srcnn_y_path_f32",
-    "srcnn_process_u8",
+    "srcnn_process_u8", "srcnn_process_u8_begin", "srcnn_process_u8_wait",
     "srcnn_delete_array", "srcnn_output_size", "srcnn_axis_table",
     "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_rank", "srcnn_comm_gather_f32",
     "srcnn_comm_gatherv_f32", "srcnn_comm_gatherv_at_f32", "srcnn_comm_tiled_y_upscale2x_f32_dev", "srcnn_band_rows", "srcnn_tiled_piece", "srcnn_debug_band_plan",
-    "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_debug_counts", "srcnn_fused_diag",
+    "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_comm_wait", "srcnn_comm_set_timeout_ms", "srcnn_debug_counts", "srcnn_fused_diag",
+    "srcnn_debug_clock_probe", "srcnn_debug_clock_read",
 ]
 CXX_SYMBOLS = ["_Z20ConfigureFilterSRCNN15SRCNNFilterTypeb", "_Z12ProcessSRCNNPKhjjjfRPhRjPS1_Pj"]
 
@@ -74,7 +76,7 @@ def lib():
             "srcnn_tiled_piece": (i, [u, u, i, i, i, i, C.POINTER(u), C.POINTER(u)]),
             "srcnn_debug_band_plan": (i, [u, u, u, i, C.POINTER(u), i]),
             "srcnn_shutdown": (None, []), "srcnn_last_error": (C.c_char_p, []), "srcnn_set_mode": (i, [i]),
-            "srcnn_get_mode": (i, []), "srcnn_device_name": (i, [C.c_char_p, sz]),
+            "srcnn_get_mode": (i, []), "srcnn_set_relaxation": (i, [u]), "srcnn_device_name": (i, [C.c_char_p, sz]),
             "srcnn_set_workspace_limit": (sz, [sz]),
             "srcnn_dev_alloc": (vp, [sz]), "srcnn_dev_free": (None, [vp]),
             "srcnn_host_alloc_pinned": (vp, [sz]), "srcnn_host_free_pinned": (None, [vp]),
@@ -87,6 +89,7 @@ def lib():
             "srcnn_stream_wait_event": (i, [vp, vp]),
             "srcnn_profile_enable": (i, [i]), "srcnn_profile_reset": (i, []),
             "srcnn_profile_read": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
+            "srcnn_profile_read_context": (i, [i, i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
             "srcnn_y_upscale2x_f32_dev": (i, [vp, u, u, vp, vp]),
             "srcnn_y_upscale2x_f32_batch_dev": (i, [vp, u, u, u, vp, vp]),
             "srcnn_y_upscale2x_f32_band_dev": (i, [vp, u, u, u, u, vp, vp]),
@@ -100,6 +103,7 @@ def lib():
             "srcnn_y_path_f32": (i, [vp, u, u, u, u, i, vp]),
             "srcnn_y_upscale2x_f32_stream": (i, [vp, u, u, u, vp, i]),
             "srcnn_process_u8": (i, [vp, u, u, u, f, i, vp, vp]),
+            "srcnn_process_u8_begin": (i, [vp, u, u, u, f, i, vp, vp, C.POINTER(vp)]), "srcnn_process_u8_wait": (i, [vp]),
             "srcnn_delete_array": (None, [vp]),
             "srcnn_output_size": (i, [u, u, f, i, C.POINTER(u), C.POINTER(u)]),
             "srcnn_axis_table": (i, [i, u, u, vp, vp, vp]),
@@ -109,7 +113,8 @@ def lib():
             "srcnn_comm_rank": (i, [C.POINTER(i), C.POINTER(i)]),
             "srcnn_debug_counts": (i, [C.POINTER(i), C.POINTER(i)]),
             "srcnn_fused_diag": (i, [vp, u, u, vp, vp, vp]),
-            "srcnn_comm_barrier": (i, [vp]),
+            "srcnn_debug_clock_probe": (i, [i]), "srcnn_debug_clock_read": (i, [i, vp, vp, i]),
+            "srcnn_comm_barrier": (i, [vp]), "srcnn_comm_wait": (i, [vp]), "srcnn_comm_set_timeout_ms": (i, [i]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -175,6 +180,14 @@ def set_mode(mode):
     return prev
 
 
+def set_relaxation(mask):
+    """Which roundings MODE_RELAXED gives up (RELAX_* bits); returns the previous mask."""
+    prev = lib().srcnn_set_relaxation(int(mask))
+    if prev < 0:
+        raise SrcnnError(prev, lib().srcnn_last_error().decode())
+    return prev
+
+
 def sync():
     check(lib().srcnn_device_sync())
 
@@ -188,6 +201,31 @@ def profile_enable(on=True):
 
 def profile_reset():
     check(lib().srcnn_profile_reset())
+
+
+def clock_probe(on=True):
+    return lib().srcnn_debug_clock_probe(1 if on else 0)
+
+
+def clock_read(context=0, cap=8192):
+    """[(MHz, microseconds)] of every layer-1+2 launch since clock_probe(True), in launch order."""
+    cyc = np.zeros(cap, np.uint64); tk = np.zeros(cap, np.uint64)
+    n = lib().srcnn_debug_clock_read(int(context), cyc.ctypes.data, tk.ctypes.data, cap)
+    if n < 0:
+        raise SrcnnError(n, lib().srcnn_last_error().decode())
+    n = min(n, cap)
+    t = np.maximum(tk[:n].astype(np.float64), 1.0)
+    return [(float(c) / float(x) * 100.0, float(x) / 100.0) for c, x in zip(cyc[:n].astype(np.float64), t)]
+
+
+def profile_read_context(k):
+    """The same for context k alone (which device of a node-level call is the straggler)."""
+    out = {}
+    for st, name in enumerate(STAGES):
+        ms, n = C.c_double(), C.c_ulonglong()
+        check(lib().srcnn_profile_read_context(int(k), st, C.byref(ms), C.byref(n)))
+        out[name] = (ms.value, n.value)
+    return out
 
 
 def profile_read():
@@ -394,6 +432,27 @@ def process_u8(rgb, multiply=2.0, filt=SRCNNF_Bicubic, want_conv=True):
     check(lib().srcnn_process_u8(rgb.ctypes.data, w, h, d, float(m), filt, out.ctypes.data,
                                  conv.ctypes.data if want_conv else None))
     return out, conv
+
+
+class ProcessJob:
+    """srcnn_process_u8_begin / _wait: the image is being produced; result() blocks and returns (rgb_out, conv_y|None)."""
+
+    def __init__(self, rgb, multiply=2.0, filt=SRCNNF_Bicubic, want_conv=True, out=None, conv=None):
+        self.rgb = np.ascontiguousarray(rgb, np.uint8)          # kept alive until the job is done
+        h, w, d = self.rgb.shape
+        m = np.float32(multiply)
+        dw, dh = int(np.float32(w) * m), int(np.float32(h) * m)
+        self.out = out if out is not None else np.empty((dh, dw, d), np.uint8)
+        self.conv = (conv if conv is not None else np.empty((dh, dw), np.uint8)) if want_conv else None
+        self.job = C.c_void_p()
+        check(lib().srcnn_process_u8_begin(self.rgb.ctypes.data, w, h, d, float(m), filt, self.out.ctypes.data,
+                                           self.conv.ctypes.data if want_conv else None, C.byref(self.job)))
+
+    def result(self):
+        if self.job is not None:
+            job, self.job = self.job, None
+            check(lib().srcnn_process_u8_wait(job))
+        return self.out, self.conv
 
 
 # ------------------------------------------------------------------------------------------------

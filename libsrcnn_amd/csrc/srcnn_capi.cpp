@@ -387,19 +387,32 @@ Workspace* workspace_for(Ctx& cx, hipStream_t s)
 void* pinned_alloc(Ctx& cx, size_t bytes)
 {
     void* p = nullptr;
-    const bool place = G.numa && cx.numa_node >= 0 && cx.numa_node < 1024;
-    unsigned long mask[16] = {0};
-    if (place) {
+    const bool want_place = G.numa && cx.numa_node >= 0 && cx.numa_node < 1024;
+    constexpr unsigned long kMaxNode = 1024;
+    unsigned long mask[kMaxNode / (8 * sizeof(unsigned long))] = {0};
+    // The policy is the CALLING thread's (an application thread inside ProcessSRCNN): whatever it was -- numactl --membind /
+    // --interleave, or one the application set itself -- is read first and put back exactly; if it cannot be read, the
+    // allocation is simply not placed.
+    int saved_mode = 0;
+    unsigned long saved_mask[kMaxNode / (8 * sizeof(unsigned long))] = {0};
+    bool placed = false;
+    if (want_place && syscall(SYS_get_mempolicy, &saved_mode, saved_mask, kMaxNode, nullptr, 0ul) == 0) {
         mask[cx.numa_node / (8 * sizeof(unsigned long))] |= 1ul << (cx.numa_node % (8 * sizeof(unsigned long)));
-        if (syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul) != 0) mask[0] = 0;
+        placed = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, kMaxNode) == 0;
     }
-    unsigned flags = hipHostMallocPortable | (place ? hipHostMallocNumaUser : 0u);
+    unsigned flags = hipHostMallocPortable | (placed ? hipHostMallocNumaUser : 0u);
     if (hipHostMalloc(&p, bytes ? bytes : 1, flags) != hipSuccess) {
         (void)hipGetLastError();
         p = nullptr;
         if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
     }
-    if (place) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+    if (placed) {
+        bool any = false;
+        for (unsigned long m : saved_mask) any = any || m != 0;
+        // MPOL_DEFAULT (and MPOL_LOCAL) take an empty node set; the others get the set they had
+        if (syscall(SYS_set_mempolicy, saved_mode, any ? saved_mask : nullptr, any ? kMaxNode : 0ul) != 0)
+            (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+    }
     if (!p) fail(SRCNN_E_DEVMEM, "hipHostMalloc(%zu) failed", bytes);
     return p;
 }
@@ -602,8 +615,13 @@ void run_conv12(const Call& c, const float* Y, int W, int H, int y_row_base, int
                 int rows)
 {
     if (c.mode == SRCNN_MODE_FAST_F16) launch_conv12_f16(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.cx->num_cus, c.s);
-    else if (G.conv12_valu) launch_conv12(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.s);
-    else launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.cx->num_cus, G.conv12_variant, c.s);
+    else if (G.conv12_valu && (c.relax() & 3) % 3 == 0) launch_conv12(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.s);
+    else {
+        unsigned long long* clk = nullptr;
+        if (G.clock_probe.load(std::memory_order_relaxed) && c.cx->clock_buf)
+            clk = c.cx->clock_buf + 2 * (size_t)(c.cx->clock_n.fetch_add(1) % kClockSlots);
+        launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.relax(), c.cx->num_cus, G.conv12_variant, c.s, clk);
+    }
 }
 
 DevAxisTable view_of(const TableRef& t) { return t->view(); }
@@ -727,7 +745,7 @@ int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw
     {
         StageTimer t(SRCNN_STAGE_CONV3, c);
         launch_conv3(ws.c2, plane, (int)dw, (int)dh, (int)ca, (int)(cb - ca), d_out, (int)r0, (int)(r1 - r0),
-                     c.strict(), c.s);
+                     c.relax(), c.s);
     }
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
@@ -904,6 +922,8 @@ void release_context(Ctx& cx)
     cx.event_pool.clear();
     (void)hipFree(cx.fused_w);
     cx.fused_w = nullptr;
+    (void)hipFree(cx.clock_buf);
+    cx.clock_buf = nullptr;
 }
 
 }  // namespace
@@ -1027,11 +1047,23 @@ int srcnn_trim(void)
 
 int srcnn_set_mode(int mode)
 {
-    if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST && mode != SRCNN_MODE_FAST_F16) return fail(SRCNN_E_ARG, "bad mode %d", mode);
-    return G.mode.exchange(mode);
+    if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST && mode != SRCNN_MODE_FAST_F16 && mode != SRCNN_MODE_RELAXED)
+        return fail(SRCNN_E_ARG, "bad mode %d", mode);
+    if (mode == SRCNN_MODE_RELAXED) mode |= (int)(G.relax_mask.load() & 0xfu) << 8;
+    return G.mode.exchange(mode) & 0xff;
 }
 
-int srcnn_get_mode(void) { return G.mode.load(); }
+int srcnn_get_mode(void) { return G.mode.load() & 0xff; }
+
+int srcnn_set_relaxation(unsigned mask)
+{
+    if (mask & ~0xfu) return fail(SRCNN_E_ARG, "bad relaxation mask 0x%x", mask);
+    if ((mask & SRCNN_RELAX_L3_X64) && (mask & SRCNN_RELAX_L3_F32)) return fail(SRCNN_E_ARG, "layer 3 can be relaxed one way at a time");
+    const unsigned prev = G.relax_mask.exchange(mask);
+    int m = G.mode.load();
+    while ((m & 0xff) == SRCNN_MODE_RELAXED && !G.mode.compare_exchange_weak(m, SRCNN_MODE_RELAXED | (int)(mask << 8))) {}
+    return (int)prev;
+}
 
 size_t srcnn_set_workspace_limit(size_t bytes)
 {
@@ -1276,6 +1308,65 @@ int srcnn_profile_read(int stage, double* total_ms, unsigned long long* launches
     return SRCNN_OK;
 }
 
+// ---- clock probe: at which shader clock did each layer-1+2 launch run? ----
+// When on, every k_conv12_mfma launch stamps s_memtime (shader cycles) and s_memrealtime (constant 100 MHz) at the start and
+// the end of its workgroup 0, which is resident for the whole launch: cycles / ticks x 100 = MHz, ticks / 100 = microseconds.
+// This is how "the same kernels run slower inside a ProcessSRCNN call" is told apart into clock and everything else
+// (tools/process_clock_probe.py, profiles/r04_process_clock.txt).
+int srcnn_debug_clock_probe(int on)
+{
+    if (int rc = ensure_init()) return rc;
+    for (int k = 0; k < context_count(); ++k) {
+        Ctx* cx = context_at(k);
+        if (!cx) continue;
+        (void)hipSetDevice(cx->device);
+        if (on && !cx->clock_buf) {
+            void* p = nullptr;
+            if (hipMalloc(&p, sizeof(unsigned long long) * 2 * kClockSlots) != hipSuccess) return fail(SRCNN_E_DEVMEM, "clock probe buffer");
+            cx->clock_buf = static_cast<unsigned long long*>(p);
+        }
+        if (cx->clock_buf) (void)hipMemset(cx->clock_buf, 0, sizeof(unsigned long long) * 2 * kClockSlots);
+        cx->clock_n = 0;
+    }
+    if (Ctx* cur = context_at(srcnn_get_context())) (void)hipSetDevice(cur->device);
+    return G.clock_probe.exchange(on != 0) ? 1 : 0;
+}
+
+// launches recorded on `context` since the probe was switched on (in launch order); writes at most `cap` (cycles, ticks) pairs
+int srcnn_debug_clock_read(int context, unsigned long long* cycles, unsigned long long* ticks, int cap)
+{
+    Ctx* cx = context_at(context);
+    if (!cx || !cx->clock_buf) return fail(SRCNN_E_ARG, "no clock probe on context %d", context);
+    (void)hipSetDevice(cx->device);
+    HIP_TRY(hipDeviceSynchronize());
+    const unsigned n = std::min(cx->clock_n.load(), kClockSlots);
+    std::vector<unsigned long long> host(2 * (size_t)n);
+    if (n) HIP_TRY(hipMemcpy(host.data(), cx->clock_buf, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost));
+    for (unsigned i = 0; i < n && (int)i < cap; ++i) {
+        if (cycles) cycles[i] = host[2 * i];
+        if (ticks) ticks[i] = host[2 * i + 1];
+    }
+    if (Ctx* cur = context_at(srcnn_get_context())) (void)hipSetDevice(cur->device);
+    return (int)n;
+}
+
+// the same for ONE context (which device is the straggler of a node-level call?)
+int srcnn_profile_read_context(int context, int stage, double* total_ms, unsigned long long* launches)
+{
+    if (stage < 0 || stage >= SRCNN_STAGE_COUNT) return fail(SRCNN_E_ARG, "bad stage %d", stage);
+    Ctx* cx = context_at(context);
+    if (!cx) return fail(SRCNN_E_ARG, "no context %d", context);
+    (void)hipSetDevice(cx->device);
+    {
+        std::lock_guard<std::mutex> lk(cx->mu);
+        drain_spans_locked(*cx);
+        if (total_ms) *total_ms = cx->stage_ms[stage];
+        if (launches) *launches = cx->stage_n[stage];
+    }
+    if (Ctx* cur = context_at(srcnn_get_context())) (void)hipSetDevice(cur->device);
+    return SRCNN_OK;
+}
+
 // ---- stage-level -------------------------------------------------------------------------------
 int srcnn_resample_f32_dev(const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
                            float* d_out, void* stream)
@@ -1318,8 +1409,9 @@ int srcnn_conv3_f32_dev(const float* d_c2, unsigned w, unsigned h, float* d_out,
     if ((rc = check_plane(d_c2, w, h, d_out))) return rc;
     if (h > 65535u * 16u) return fail(SRCNN_E_UNSUPPORTED, "too many rows");
     if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
-    launch_conv3(d_c2, (size_t)w * h, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, G.mode.load() == SRCNN_MODE_STRICT,
-                 (hipStream_t)stream);
+    Call c;
+    c.mode = G.mode.load();
+    launch_conv3(d_c2, (size_t)w * h, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, c.relax(), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
 }

@@ -9,10 +9,15 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/srcnn_amd.h"
@@ -35,6 +40,7 @@ struct Rccl {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;           // optional: what a missed deadline calls to free stuck ranks
 };
 
 Rccl R;
@@ -45,6 +51,85 @@ float* g_token = nullptr;
 hipStream_t g_comm_stream = nullptr;    // the tiled path's gathers run here, beside the compute stream
 std::vector<hipEvent_t> g_events;       // sub-band "kernels queued" events + one "gathers done" event
 std::mutex g_mu;
+std::vector<unsigned long long> g_verified;   // checksums of the tables every rank was seen to agree on (bounded)
+unsigned long long* g_check = nullptr;  // SRCNN_COMM_CHECK: two device words for the min/max all-reduce of a table's checksum
+std::atomic<bool> g_poisoned{false};    // a deadline was missed: the communicator was aborted, every later call fails at once
+
+// ---- deadlines -------------------------------------------------------------------------------------------------------
+// Nothing in this file may wait for a peer without a bound: a rank that died, or one that derived a different counts table,
+// would otherwise leave every other rank of the job hanging inside RCCL (ncclGroupEnd blocks on the host while connections
+// are set up; a send / recv kernel spins on the device until its peer shows up).  Two mechanisms:
+//   * host side: Watchdog -- armed around every RCCL call that can block; when the deadline passes it calls ncclCommAbort
+//     (the one RCCL call that is allowed from another thread and makes blocked calls return) and marks the communicator dead;
+//   * device side: wait_stream_deadline() -- a polled wait for everything queued on a stream, used by srcnn_comm_barrier and
+//     srcnn_comm_wait; on a miss it aborts the communicator the same way, which also ends the spinning kernels.
+// SRCNN_COMM_TIMEOUT_MS / srcnn_comm_set_timeout_ms: default 60 s; 0 = wait for ever (the round-3 behaviour).
+std::atomic<int> g_timeout_ms{[] { const char* e = getenv("SRCNN_COMM_TIMEOUT_MS"); return e ? std::max(0, atoi(e)) : 60000; }()};
+
+void abort_comm(ncclComm_t comm)
+{
+    g_poisoned = true;
+    if (R.CommAbort && comm) (void)R.CommAbort(comm);
+}
+
+class Watchdog {
+public:
+    // arm() .. disarm() brackets one blocking call; returns through `fired` whether the deadline hit
+    void arm(ncclComm_t comm)
+    {
+        const int ms = g_timeout_ms.load();
+        if (ms <= 0) return;
+        std::lock_guard<std::mutex> lk(m_);
+        if (!started_) { th_ = std::thread([this] { run(); }); th_.detach(); started_ = true; }
+        comm_ = comm; fired_ = false; armed_ = true;
+        deadline_ = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
+        cv_.notify_all();
+    }
+    bool disarm()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        armed_ = false;
+        cv_.notify_all();
+        return fired_;
+    }
+private:
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [&] { return armed_; });
+            while (armed_ && cv_.wait_until(lk, deadline_) != std::cv_status::timeout) {}
+            if (armed_ && std::chrono::steady_clock::now() >= deadline_) {
+                fired_ = true; armed_ = false;
+                ncclComm_t c = comm_;
+                lk.unlock();
+                abort_comm(c);
+                lk.lock();
+            }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;
+    bool started_ = false, armed_ = false, fired_ = false;
+    ncclComm_t comm_ = nullptr;
+    std::chrono::steady_clock::time_point deadline_;
+};
+Watchdog& watchdog() { static Watchdog* w = new Watchdog; return *w; }      // (never destroyed: its thread outlives main)
+
+// everything queued on `s` has completed, or the deadline passed (then the communicator is aborted): hipSuccess / hipErrorNotReady
+hipError_t wait_stream_deadline(hipStream_t s, ncclComm_t comm)
+{
+    const int ms = g_timeout_ms.load();
+    if (ms <= 0) return srcnn::wait_stream(s);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
+    for (int n = 0;; ++n) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() >= deadline) { abort_comm(comm); return hipErrorNotReady; }
+        if (n > 64) std::this_thread::sleep_for(std::chrono::microseconds(n < 2000 ? 50 : 500));
+    }
+}
 
 // A consistent view of the communicator for one call (taken under g_mu; the collective itself runs outside it so that a
 // rank blocked in RCCL never blocks srcnn_comm_rank on another thread).
@@ -91,6 +176,7 @@ int load()
     SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(GroupStart) SYM(GroupEnd)
     SYM(Send) SYM(Recv) SYM(AllGather) SYM(AllReduce) SYM(GetErrorString)
 #undef SYM
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));      // optional
     if (missing) {      // leave R untouched so that the next call reports the same failure instead of calling NULL
         snprintf(g_cerr, sizeof g_cerr, "librccl lacks %s", missing);
         srcnn::set_last_error(g_cerr);
@@ -107,6 +193,19 @@ int comm_fail(const char* what)
     snprintf(g_cerr, sizeof g_cerr, "%s", what);
     srcnn::set_last_error(g_cerr);
     return SRCNN_E_COMM;
+}
+
+int poisoned_fail()
+{
+    return comm_fail("the communicator was aborted after a missed deadline (SRCNN_COMM_TIMEOUT_MS): destroy and re-create it");
+}
+
+// FNV-1a over the bytes of a table: what SRCNN_COMM_CHECK=1 compares across the ranks before a gather trusts it
+unsigned long long fnv1a(const void* p, size_t n, unsigned long long h = 1469598103934665603ull)
+{
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
 }
 
 #define NCCL_TRY(expr)                                                                         \
@@ -178,8 +277,11 @@ int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int n
         srcnn::set_last_error("srcnn_comm_init: device allocation failed");
         return SRCNN_E_DEVMEM;
     }
+    if (hipMalloc((void**)&g_check, 2 * sizeof(unsigned long long)) != hipSuccess) g_check = nullptr;    // SRCNN_COMM_CHECK only
     g_comm = comm; g_token = token;
     g_rank = rank; g_nranks = nranks; g_device = cx->device;
+    g_poisoned = false;
+    g_verified.clear();
     return SRCNN_OK;
 }
 
@@ -188,10 +290,17 @@ int srcnn_comm_destroy(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_comm) return SRCNN_OK;
     (void)hipSetDevice(g_device);
-    hipDeviceSynchronize();
-    R.CommDestroy(g_comm);
+    if (g_poisoned.load()) {
+        // aborted after a missed deadline: its kernels have been told to quit; a destroy would wait for peers that are gone
+        if (R.CommAbort) (void)R.CommAbort(g_comm);
+    } else {
+        hipDeviceSynchronize();
+        R.CommDestroy(g_comm);
+    }
     g_comm = nullptr;
     hipFree(g_token); g_token = nullptr;
+    hipFree(g_check); g_check = nullptr;
+    g_poisoned = false;
     for (auto e : g_events) (void)hipEventDestroy(e);
     g_events.clear();
     if (g_comm_stream) (void)hipStreamDestroy(g_comm_stream);
@@ -209,21 +318,68 @@ int srcnn_comm_rank(int* rank, int* nranks)
     return SRCNN_OK;
 }
 
-// counts[r] floats from rank r land at d_recv + offsets[r] on the root.  counts / offsets must be identical on every rank
-// (a mismatch would hang in GroupEnd; the callers in this library derive them from (height, nranks) alone).
+namespace {
+// SRCNN_COMM_CHECK=1: before a gather trusts a counts / offsets table, every rank contributes the table's checksum to a
+// min/max all-reduce; ranks that derived different tables (which would otherwise pair a send with a receive of another size
+// and hang or corrupt) all return SRCNN_E_COMM instead.  A table that was seen to agree is not checked again.
+int verify_table(const CommView& v, unsigned long long h, hipStream_t s)
+{
+    static const bool on = [] { const char* e = getenv("SRCNN_COMM_CHECK"); return e && atoi(e) != 0; }();
+    if (!on) return SRCNN_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (std::find(g_verified.begin(), g_verified.end(), h) != g_verified.end()) return SRCNN_OK;
+        if (!g_check) return comm_fail("SRCNN_COMM_CHECK: no device words for the checksum");
+    }
+    unsigned long long words[2] = {h, ~h};                   // min(h) and min(~h) = ~max(h)
+    if (hipMemcpyAsync(g_check, words, sizeof words, hipMemcpyHostToDevice, s) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: upload failed");
+    watchdog().arm(v.comm);
+    const ncclResult_t r = R.AllReduce(g_check, g_check, 2, ncclUint64, ncclMin, v.comm, s);
+    const bool late = watchdog().disarm();
+    if (late || r != ncclSuccess) return comm_fail(late ? "SRCNN_COMM_CHECK: all-reduce missed its deadline" : "SRCNN_COMM_CHECK: all-reduce failed");
+    if (wait_stream_deadline(s, v.comm) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: a rank never arrived (deadline)");
+    if (hipMemcpy(words, g_check, sizeof words, hipMemcpyDeviceToHost) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: read-back failed");
+    if (words[0] != ~words[1]) {
+        snprintf(g_cerr, sizeof g_cerr, "SRCNN_COMM_CHECK: the ranks disagree about the gather table (this rank %016llx, min %016llx, max %016llx)",
+                 h, words[0], ~words[1]);
+        srcnn::set_last_error(g_cerr);
+        return SRCNN_E_COMM;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_verified.size() >= 256) g_verified.clear();
+    g_verified.push_back(h);
+    return SRCNN_OK;
+}
+
+unsigned long long table_hash(const size_t* counts, const size_t* offsets, int nranks, int root)
+{
+    unsigned long long h = fnv1a(counts, sizeof(size_t) * (size_t)nranks);
+    h = fnv1a(offsets, sizeof(size_t) * (size_t)nranks, h);
+    const int tail[2] = {nranks, root};
+    return fnv1a(tail, sizeof tail, h);
+}
+}  // namespace
+
+// counts[r] floats from rank r land at d_recv + offsets[r] on the root.  counts / offsets must be identical on every rank: the
+// callers in this library derive them from (width, height, nranks, pieces) alone; SRCNN_COMM_CHECK=1 verifies that across the
+// ranks before the first gather with a given table.  A mismatch that slips through, or a rank that died, cannot hang the
+// others for ever: the group is issued under the watchdog's deadline (see above) and the caller waits with srcnn_comm_wait.
 int srcnn_comm_gatherv_at_f32(const float* d_send, const size_t* counts, const size_t* offsets, float* d_recv, int root,
                               void* stream)
 {
     CommView v;
     if (!view(v)) return comm_fail("no communicator");
+    if (g_poisoned.load()) return poisoned_fail();
     if (!counts || !offsets || root < 0 || root >= v.nranks) return comm_fail("srcnn_comm_gatherv_at_f32: bad counts / offsets / root");
     if (counts[v.rank] && !d_send) return comm_fail("srcnn_comm_gatherv_at_f32: d_send == NULL");
     if (v.rank == root && !d_recv) return comm_fail("srcnn_comm_gatherv_at_f32: d_recv == NULL on the root");
     if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = verify_table(v, table_hash(counts, offsets, v.nranks, root), s)) return rc;
     // every Send/Recv of the group is attempted and GroupEnd always runs, so a failure never leaves the group open
     ncclResult_t first_bad = ncclSuccess;
     auto note = [&](ncclResult_t r) { if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r; };
+    watchdog().arm(v.comm);
     note(R.GroupStart());
     if (v.rank == root) {
         for (int r = 0; r < v.nranks; ++r)
@@ -232,6 +388,7 @@ int srcnn_comm_gatherv_at_f32(const float* d_send, const size_t* counts, const s
         note(R.Send(d_send, counts[v.rank], ncclFloat, root, v.comm, s));
     }
     note(R.GroupEnd());
+    if (watchdog().disarm()) return comm_fail("band gather: a peer did not arrive before the deadline (SRCNN_COMM_TIMEOUT_MS); communicator aborted");
     if (first_bad != ncclSuccess) {
         snprintf(g_cerr, sizeof g_cerr, "band gather failed: %s", R.GetErrorString(first_bad));
         srcnn::set_last_error(g_cerr);
@@ -299,6 +456,7 @@ int srcnn_comm_tiled_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned
 {
     CommView v;
     if (!view(v)) return comm_fail("no communicator");
+    if (g_poisoned.load()) return poisoned_fail();
     if (!d_in || w == 0 || h == 0) return comm_fail("srcnn_comm_tiled: NULL pointer or zero dimension");
     if (root < 0 || root >= v.nranks) return comm_fail("srcnn_comm_tiled: bad root");
     if (v.rank == root && !d_full) return comm_fail("srcnn_comm_tiled: d_full == NULL on the root");
@@ -352,8 +510,12 @@ int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, v
 {
     CommView v;
     if (!view(v)) return comm_fail("no communicator");
+    if (g_poisoned.load()) return poisoned_fail();
     if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
-    NCCL_TRY(R.AllGather(d_send, d_recv, count, ncclFloat, v.comm, (hipStream_t)stream));
+    watchdog().arm(v.comm);
+    const ncclResult_t r = R.AllGather(d_send, d_recv, count, ncclFloat, v.comm, (hipStream_t)stream);
+    if (watchdog().disarm()) return comm_fail("all-gather: deadline missed while queueing; communicator aborted");
+    NCCL_TRY(r);
     return SRCNN_OK;
 }
 
@@ -361,10 +523,38 @@ int srcnn_comm_barrier(void* stream)
 {
     CommView v;
     if (!view(v)) return comm_fail("no communicator");
+    if (g_poisoned.load()) return poisoned_fail();
     if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
-    NCCL_TRY(R.AllReduce(g_token, g_token, 1, ncclFloat, ncclSum, v.comm, (hipStream_t)stream));
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SRCNN_E_HIP;
+    watchdog().arm(v.comm);
+    const ncclResult_t r = R.AllReduce(g_token, g_token, 1, ncclFloat, ncclSum, v.comm, (hipStream_t)stream);
+    if (watchdog().disarm()) return comm_fail("barrier: deadline missed while queueing; communicator aborted");
+    NCCL_TRY(r);
+    return srcnn_comm_wait(stream);
+}
+
+// Host wait for everything queued on `stream` (NULL = the default stream) -- what a caller uses instead of srcnn_stream_sync
+// after srcnn_comm_tiled_y_upscale2x_f32_dev / a gather: bounded by the deadline.  On a miss the communicator is aborted
+// (which also ends send / recv kernels spinning for a peer that never came) and SRCNN_E_COMM is returned; every later
+// srcnn_comm_* call then fails at once until the communicator is destroyed and re-created.
+int srcnn_comm_wait(void* stream)
+{
+    CommView v;
+    if (!view(v)) return comm_fail("no communicator");
+    if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
+    const hipError_t e = wait_stream_deadline((hipStream_t)stream, v.comm);
+    if (e == hipErrorNotReady)
+        return comm_fail("srcnn_comm_wait: the stream did not drain before the deadline (SRCNN_COMM_TIMEOUT_MS): a peer is missing or the ranks "
+                         "disagree about a gather; communicator aborted");
+    if (e != hipSuccess) { srcnn::set_last_error(hipGetErrorString(e)); return SRCNN_E_HIP; }
+    if (g_poisoned.load()) return poisoned_fail();
     return SRCNN_OK;
+}
+
+// deadline for every wait on a peer, in milliseconds (0: none); returns the previous value
+int srcnn_comm_set_timeout_ms(int ms)
+{
+    if (ms < 0) return comm_fail("srcnn_comm_set_timeout_ms: negative");
+    return g_timeout_ms.exchange(ms);
 }
 
 }  // extern "C"

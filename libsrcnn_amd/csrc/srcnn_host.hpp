@@ -90,10 +90,20 @@ struct Call {
     Ctx* cx = nullptr;
     hipStream_t s = nullptr;
     Workspace* ws = nullptr;
-    int mode = SRCNN_MODE_STRICT;
+    int mode = SRCNN_MODE_STRICT;       // SRCNN_MODE_* in the low byte; for SRCNN_MODE_RELAXED the SRCNN_RELAX_* mask in bits 8..11
     bool timing = true;
     std::vector<TableRef>* hold = nullptr;
     bool strict() const { return mode == SRCNN_MODE_STRICT; }
+    int tier() const { return mode & 0xff; }
+    // the roundings this call gives up, as RELAX_* bits for the layer launchers (0 = strict)
+    int relax() const
+    {
+        switch (mode & 0xff) {
+        case SRCNN_MODE_STRICT: return 0;
+        case SRCNN_MODE_RELAXED: return (mode >> 8) & 0xf;
+        default: return RELAX_FAST;
+        }
+    }
 };
 
 struct StageSpan { hipEvent_t a, b; int stage; };
@@ -128,6 +138,7 @@ struct ProcLane {
     void release();
 };
 constexpr size_t kDefaultMaxLanes = 4;   // per context; env SRCNN_MAX_LANES (1..64) overrides
+constexpr unsigned kClockSlots = 8192;   // layer-1+2 launches the clock probe can hold before it wraps
 constexpr size_t kMaxTables = 64;      // cache bound per context; only unreferenced tables are ever evicted
 
 // Per-context buffers of the node-level tiled frame (srcnn_y_upscale2x_f32_node_dev): the slab of the source frame this
@@ -151,6 +162,8 @@ struct Ctx {
     double stage_ms[SRCNN_STAGE_COUNT] = {0, 0, 0};
     unsigned long long stage_n[SRCNN_STAGE_COUNT] = {0, 0, 0};
     int num_cus = 256;
+    unsigned long long* clock_buf = nullptr;   // srcnn_debug_clock_probe: kClockSlots x (cycles, ticks), one slot per conv12 launch
+    std::atomic<unsigned> clock_n{0};
     FusedF16Weights* fused_w = nullptr;   // device copy of the fused fp16 kernel's weight image
     std::map<std::tuple<int, unsigned, unsigned>, TableRef> tables;
     unsigned long long table_clock = 0;
@@ -170,7 +183,9 @@ struct Global {
     std::atomic<int> nctx{0};                        // == ctxs.size(), readable without the lock
     std::map<hipStream_t, int> stream_ctx;           // streams made by srcnn_stream_create -> owning context
     std::atomic<bool> profiling{false};
-    std::atomic<int> mode{SRCNN_MODE_STRICT};
+    std::atomic<bool> clock_probe{false};            // srcnn_debug_clock_probe
+    std::atomic<int> mode{SRCNN_MODE_STRICT};        // as Call::mode (tier in the low byte, relaxation mask above it)
+    std::atomic<unsigned> relax_mask{SRCNN_RELAX_L3_X64};   // what SRCNN_MODE_RELAXED relaxes (srcnn_set_relaxation)
     std::atomic<size_t> ws_budget;
     int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
     bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)

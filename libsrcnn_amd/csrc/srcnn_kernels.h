@@ -8,6 +8,14 @@ namespace srcnn {
 
 constexpr int C1N = 64;   // layer-1 feature maps   (reference: CONV1_FILTERS, src/convdata.h:5)
 constexpr int C2N = 32;   // layer-2 feature maps   (reference: CONV2_FILTERS, src/convdata.h:8)
+// Which of the reference's roundings a call gives up (bitmask; 0 = strict = bit-exact).  See DESIGN.md "numerics contract".
+enum : int {
+    RELAX_L1 = 1,        // layer 1 as an FMA chain on the fp32 MFMA (C = acc): one rounding per tap instead of two
+    RELAX_L2 = 2,        // layer 2 likewise
+    RELAX_L3_X64 = 4,    // layer 3 with exact products (v_fma_f64 on widened operands); sums as the reference's
+    RELAX_L3_F32 = 8,    // layer 3 as fp32 FMA chains (k_conv3_fast)
+    RELAX_FAST = RELAX_L1 | RELAX_L2 | RELAX_L3_F32
+};
 constexpr int kWeightCount = 64 + 64 * 81 + 32 + 32 * 64 + 1 + 32 * 25;   // 8129
 
 // Device-side weight image (one __constant__ instance).  See srcnn_kernels.hip header for the
@@ -104,14 +112,17 @@ bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int 
 void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                    int out_rows, bool strict, hipStream_t s);
 hipError_t conv12_mfma_prepare();
+// relax: RELAX_L1 | RELAX_L2 bits (0 = strict); the single-layer forms always take the production geometry (variant 1)
+// clk: NULL, or two device words that receive (shader-clock cycles, 100 MHz ticks) of workgroup 0's lifetime
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                        int out_rows, bool strict, int num_cus, int variant, hipStream_t s);
+                        int out_rows, int relax, int num_cus, int variant, hipStream_t s, unsigned long long* clk = nullptr);
 void conv12_grid_info(int num_cus, int variant, int* blocks, int* tile_rows);
 hipError_t conv12_f16_prepare();
 void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
                        int out_rows, int num_cus, hipStream_t s);
+// relax: RELAX_L3_X64 / RELAX_L3_F32 bits (neither = strict)
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
-                  int out_row0, int out_rows, bool strict, hipStream_t s);
+                  int out_row0, int out_rows, int relax, hipStream_t s);
 void launch_conv1_planes(const float* Y, int W, int H, float* C1, hipStream_t s);
 void launch_conv2_planes(const float* C1, size_t n, float* C2v, hipStream_t s);
 void launch_rgb_split(const unsigned char* rgb, size_t n, int d, float* Yp, float* Cb, float* Cr, float* A,

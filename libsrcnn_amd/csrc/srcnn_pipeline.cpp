@@ -323,7 +323,9 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     }
     // The fused shell reads the interleaved source directly (no split, no destination-size chroma planes); it needs an
     // up-scale in both axes with short monotone tables -- anything else takes the plane path below.
-    bool fused_shell = !G.shell_unfused && !identity && dw > w && dh > h;
+    // (the fused shell feeds the Y path an RGB source, which only k_rs2d can read: the switches that force the older plane
+    //  resamplers therefore select the plane shell as well)
+    bool fused_shell = !G.shell_unfused && !G.resample_two_pass && !G.resample_old2d && !identity && dw > w && dh > h;
     if (fused_shell) {
         if ((rc = get_table(c, J.cfilter, dw, w, ch_))) return rc;
         if ((rc = get_table(c, J.filter, dh, h, yv))) return rc;
@@ -355,7 +357,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 
     // ---- bands ----
     int grid = 0, tile_rows = 0;
-    if (J.mode == SRCNN_MODE_STRICT && !G.conv12_valu) conv12_grid_info(cx.num_cus, G.conv12_variant, &grid, &tile_rows);
+    if ((J.mode & 0xff) != SRCNN_MODE_FAST_F16 && !G.conv12_valu) conv12_grid_info(cx.num_cus, G.conv12_variant, &grid, &tile_rows);
     const std::vector<unsigned> cuts = band_starts(R0, R1, dw, dh, one_of_many, grid, tile_rows);
     const unsigned nb = (unsigned)cuts.size() - 1;
     unsigned max_band = 0;
@@ -695,6 +697,55 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     for (unsigned k = 0; k < shares; ++k)
         if (rcs[k]) { set_last_error(errs[k].c_str()); return rcs[k]; }
     return SRCNN_OK;
+}
+
+// ---- the same call, asynchronous: begin() returns at once, wait() joins ----
+// A caller that upscales a SEQUENCE of images keeps the device busy across calls this way: while image i's last band is
+// copied out and fanned into its result buffer (the tail of the call, ~1 ms at 4K during which a synchronous caller's GPU
+// idles, and after which the same kernels run 9-15 % slower for a while: DESIGN.md 4.5), image i+1's stage-in and first
+// bands are already queued on another lane.  Each job runs srcnn_process_u8 on a thread of its own with the caller's
+// current context; up to SRCNN_MAX_LANES jobs per context make progress at once, further ones queue for a lane like
+// concurrent synchronous callers do.  The buffers must stay valid and untouched until wait() returns.
+namespace {
+struct AsyncJob {
+    std::thread th;
+    int rc = SRCNN_OK;
+    std::string err;
+};
+}  // namespace
+
+int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
+                           unsigned char* out, unsigned char* conv_opt, void** job)
+{
+    if (!job) return fail(SRCNN_E_ARG, "job == NULL");
+    *job = nullptr;
+    Ctx* cur = cur_ctx();
+    if (!cur) return SRCNN_E_NODEVICE;
+    const int ctx_index = cur->index;
+    AsyncJob* a = new (std::nothrow) AsyncJob;
+    if (!a) return fail(SRCNN_E_OUTALLOC, "out of memory");
+    const bool ok = try_thread(a->th, [=] {
+        (void)srcnn_set_context(ctx_index);                   // the worker inherits the caller's current context
+        a->rc = srcnn_process_u8(rgb, w, h, d, multiply, filter, out, conv_opt);
+        if (a->rc) a->err = srcnn_last_error();
+    });
+    if (!ok) {                                                // no thread to be had: degrade to the synchronous call
+        a->rc = srcnn_process_u8(rgb, w, h, d, multiply, filter, out, conv_opt);
+        if (a->rc) a->err = srcnn_last_error();
+    }
+    *job = a;
+    return SRCNN_OK;
+}
+
+int srcnn_process_u8_wait(void* job)
+{
+    if (!job) return fail(SRCNN_E_ARG, "job == NULL");
+    AsyncJob* a = static_cast<AsyncJob*>(job);
+    if (a->th.joinable()) a->th.join();
+    const int rc = a->rc;
+    if (rc) set_last_error(a->err.c_str());
+    delete a;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

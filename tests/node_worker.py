@@ -177,7 +177,21 @@ def cmd_comm_tiled(_):
     S.sync()
     got = dst.to_numpy(np.float32, (3 * n,))
     res["gatherv_at"] = bool(np.array_equal(got[1500:2500], np.arange(n, dtype=np.float32)) and not got[:1500].any() and not got[2500:].any())
+    # the bounded waits: srcnn_comm_wait drains a stream inside the deadline; the setter returns the previous value; the
+    # barrier (which waits through srcnn_comm_wait) still works with a short deadline and with none
+    prev = L.srcnn_comm_set_timeout_ms(5000)
+    res["timeout_prev"] = prev
+    st = S.Stream()
+    S.check(L.srcnn_comm_gatherv_at_f32(src.ptr, counts, offs, dst.ptr, 0, st.handle))
+    res["comm_wait"] = L.srcnn_comm_wait(st.handle)
+    res["barrier_short_deadline"] = L.srcnn_comm_barrier(None)
+    res["timeout_prev2"] = L.srcnn_comm_set_timeout_ms(0)
+    res["barrier_no_deadline"] = L.srcnn_comm_barrier(None)
+    L.srcnn_comm_set_timeout_ms(prev)
+    res["comm_check_env"] = os.environ.get("SRCNN_COMM_CHECK", "")
+    st.destroy()
     L.srcnn_comm_destroy()
+    res["wait_without_comm"] = L.srcnn_comm_wait(None)
     return res
 
 

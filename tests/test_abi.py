@@ -39,7 +39,7 @@ def test_reference_cxx_symbols_exported(S):
     L = S.lib()
     for sym in S.CXX_SYMBOLS:
         assert hasattr(L, sym), sym
-    assert L.srcnn_abi_version() == 3
+    assert L.srcnn_abi_version() == 4
 
 
 def test_reference_argument_checks_need_no_device(S):

@@ -49,10 +49,18 @@ def test_host_stream_dealt_over_contexts():
     assert r["contexts"] == 2 and all(r["equal"]) and r["single_frame"], r
 
 
-def test_rccl_tiled_call_with_overlapped_sub_band_gather():
-    r = run("comm_tiled")
+@pytest.mark.parametrize("check", ["", "1"], ids=["plain", "SRCNN_COMM_CHECK"])
+def test_rccl_tiled_call_with_overlapped_sub_band_gather(check):
+    """World = 1 is all a one-GPU box can run: every sub-band count and ragged heights, the explicit-offset gather, the
+    bounded waits (srcnn_comm_wait / srcnn_comm_set_timeout_ms), and -- second run -- the same with every gather table
+    first verified across the ranks by a checksum all-reduce (SRCNN_COMM_CHECK=1)."""
+    r = run("comm_tiled", env={"SRCNN_COMM_CHECK": check})
     assert all(c["equal"] for c in r["cases"]), r
     assert r["gatherv_at"]
+    assert r["comm_check_env"] == check
+    assert r["timeout_prev"] == 60000 and r["timeout_prev2"] == 5000, r
+    assert r["comm_wait"] == 0 and r["barrier_short_deadline"] == 0 and r["barrier_no_deadline"] == 0, r
+    assert r["wait_without_comm"] == -204, r
 
 
 def test_more_callers_than_lanes_queue_up():

@@ -537,6 +537,40 @@ def test_whole_1080p_frame_against_the_compiled_reference(srcnn):
     assert_bit_equal(got, want, "whole 1080p frame, seed %d" % seed)
 
 
+def test_whole_4k_frame_every_sample_vs_reference(srcnn):
+    """The headline workload itself: every one of the 33.2 M samples of a 3840x2160 -> 7680x4320 frame against the REAL
+    reference (oracle/_ref = /root/reference/src/libsrcnn.cpp:785-846 compiled in the dev container; the C restatement where
+    that did not travel).  The reference holds ~100 full-size planes (~17 GB): with less than 32 GB of free host memory the
+    frame is checked as two half-frames with a 16-row input overlap instead (the path's receptive field is +-5 input rows,
+    so the rows kept from each half are the whole-frame rows -- the same crop argument as tests/test_gpu_configs.py).  The
+    seed changes from run to run (printed; SRCNN_TEST_SEED replays)."""
+    import os
+    import time
+    import oracle
+    eng = oracle.Reference() if oracle.have_reference() else oracle.Oracle()
+    seed = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(time.time()) & 0xFFFFF)
+    h, w = 2160, 3840
+    y = synth.plane(h, w, synth.SEED0 + 7 * seed + 1, "smooth" if seed & 1 else "noise")
+    got = srcnn.y_upscale2x(y)
+    free_gb = 0.0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            free_gb = int(line.split()[1]) / 2 ** 20
+    t0 = time.time()
+    if free_gb >= 32.0:
+        want = eng.y_path(y)
+        print("whole 4K frame: seed", seed, "engine", type(eng).__name__, "one piece, %.1f s" % (time.time() - t0))
+        assert_bit_equal(got, want, "whole 4K frame, seed %d" % seed)
+    else:
+        mid, pad = h // 2, 16
+        top = eng.y_path(np.ascontiguousarray(y[:mid + pad]))[:2 * mid]
+        assert_bit_equal(got[:2 * mid], top, "4K frame, top half, seed %d" % seed)
+        del top
+        bot = eng.y_path(np.ascontiguousarray(y[mid - pad:]))[2 * pad:]
+        print("whole 4K frame: seed", seed, "engine", type(eng).__name__, "two halves (%.0f GB free), %.1f s" % (free_gb, time.time() - t0))
+        assert_bit_equal(got[2 * mid:], bot, "4K frame, bottom half, seed %d" % seed)
+
+
 def test_stream_graph_then_eager_with_a_larger_workspace_limit(srcnn):
     """a use_graph=0 call that follows a use_graph=1 call of the same shape must not trip over the graph's frozen
     workspace when the scratch limit has been raised in between, must not leave a graph replaying freed tables, and a later

@@ -1,0 +1,137 @@
+"""GPU tests of what round 4 added: the per-layer relaxation instrument (SRCNN_MODE_RELAXED), the asynchronous
+ProcessSRCNN pair (srcnn_process_u8_begin / _wait), the per-context profile read, and the NUMA placement of page-locked
+staging leaving the caller's memory policy alone.  Strict results are the oracle's bits; relaxed results are held to the
+bounds measured in profiles/r04_error_matrix.txt (none of them is a parity tier -- DESIGN.md 3)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from libsrcnn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_NORTH_STAR = 1e-4          # BASELINE.json: |dY| <= 1e-4 on the 0..255 scale
+# what each relaxation may cost (measured maxima on whole 4K->8K frames, 16 seeds x 2 generators, with head-room):
+RELAX_BOUND = {1: 4e-4, 2: 3e-4, 4: 2.5e-4, 8: 3e-4, 3: 4e-4, 7: 4e-4, 11: 4e-4}
+
+
+def test_relaxed_mode_with_empty_mask_is_strict_and_masks_are_validated(srcnn, oracle_lib):
+    S = srcnn
+    y = synth.plane(70, 90, synth.SEED0 + 41, "noise")
+    want = oracle_lib.y_path(y)
+    prev_mask = S.set_relaxation(0)
+    prev = S.set_mode(S.MODE_RELAXED)
+    try:
+        assert S.lib().srcnn_get_mode() == S.MODE_RELAXED
+        assert_bit_equal(S.y_upscale2x(y), want, "MODE_RELAXED with no layer relaxed")
+        assert S.lib().srcnn_set_relaxation(16) < 0                       # unknown bit
+        assert S.lib().srcnn_set_relaxation(4 | 8) < 0                    # layer 3 both ways at once
+        assert S.lib().srcnn_set_mode(9) < 0
+    finally:
+        S.set_mode(prev)
+        S.set_relaxation(prev_mask)
+    assert_bit_equal(S.y_upscale2x(y), want, "strict after the round trip")
+
+
+@pytest.mark.parametrize("mask", sorted(RELAX_BOUND))
+def test_each_relaxation_moves_the_result_by_a_little_and_only_when_asked(srcnn, oracle_lib, mask):
+    """Every SRCNN_RELAX_* combination: differs from the reference (otherwise the switch is not wired), stays inside its measured
+    bound on a 960x540 -> 1920x1080 frame, bands of the frame equal the same rows of the whole frame bit for bit (same kernels,
+    same arithmetic per sample), and the next strict call is bit-exact again."""
+    S = srcnn
+    y = synth.plane(540, 960, synth.SEED0 + 42, "noise" if mask & 1 else "smooth")
+    prev_mask = S.set_relaxation(mask)
+    prev = S.set_mode(S.MODE_RELAXED)
+    try:
+        got = S.y_upscale2x(y)
+        band = S.y_upscale2x_band(y, 333, 500)
+    finally:
+        S.set_mode(prev)
+        S.set_relaxation(prev_mask)
+    strict = S.y_upscale2x(y)
+    h, w = y.shape
+    # strict == the oracle on a window (whole-frame strict parity is tests/test_gpu_parity.py's business)
+    win = oracle_lib.y_path(np.ascontiguousarray(y[100:180, 200:300]))[32:-32, 32:-32]
+    assert_bit_equal(strict[232:232 + win.shape[0], 432:432 + win.shape[1]], win, "strict window")
+    d = np.abs(got.astype(np.float64) - strict)
+    assert d.max() > 0, "mask %d changed nothing" % mask
+    assert d.max() <= RELAX_BOUND[mask], (mask, d.max())
+    assert_bit_equal(band, got[333:833], "relaxed band vs relaxed whole frame, mask %d" % mask)
+
+
+def test_async_process_jobs_keep_several_images_in_flight(srcnn, oracle_lib, golden):
+    """srcnn_process_u8_begin / _wait: three jobs in flight at once (a banded 1080p image twice, the butterfly once), each equal
+    to the oracle's bytes; errors surface in wait(); a NULL job is refused."""
+    S = srcnn
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    fly = golden.butterfly["rgb_in"].reshape(256, 256, 3)
+    want_big = oracle_lib.process(big, 2.0)
+    want_fly = oracle_lib.process(fly, 2.0)
+    for _ in range(3):
+        jobs = [S.ProcessJob(big), S.ProcessJob(fly), S.ProcessJob(big, want_conv=False)]
+        r0, r1, r2 = [j.result() for j in jobs]
+        assert np.array_equal(r0[0], want_big[0]) and np.array_equal(r0[1], want_big[1])
+        assert np.array_equal(r1[0], want_fly[0]) and np.array_equal(r1[1], want_fly[1])
+        assert np.array_equal(r2[0], want_big[0]) and r2[1] is None
+    # an argument error comes back from wait(), with its text
+    L = S.lib()
+    job = C.c_void_p()
+    out = np.empty(16, np.uint8)
+    assert L.srcnn_process_u8_begin(big.ctypes.data, 4, 4, 2, 2.0, 2, out.ctypes.data, None, C.byref(job)) == 0
+    assert L.srcnn_process_u8_wait(job) == -203 and b"depth" in L.srcnn_last_error()
+    assert L.srcnn_process_u8_wait(None) == -1
+    assert L.srcnn_process_u8_begin(big.ctypes.data, 4, 4, 3, 2.0, 2, out.ctypes.data, None, None) == -1
+
+
+def test_profile_read_per_context(srcnn):
+    S = srcnn
+    y = synth.plane(64, 96, 3, "noise")
+    S.profile_reset(); S.profile_enable(True)
+    for _ in range(3):
+        S.y_upscale2x(y)
+    S.profile_enable(False)
+    per = S.profile_read_context(0)
+    tot = S.profile_read()
+    assert per["conv12"][1] == tot["conv12"][1] == 3 and per["conv3"][1] == 3
+    assert abs(per["conv12"][0] - tot["conv12"][0]) < 1e-6
+    assert S.lib().srcnn_profile_read_context(7, 0, None, None) == -1
+
+
+def _mempolicy():
+    libc = C.CDLL(None, use_errno=True)
+    mode = C.c_int(-1)
+    mask = (C.c_ulong * 16)()
+    rc = libc.syscall(239, C.byref(mode), mask, C.c_ulong(1024), None, C.c_ulong(0))      # SYS_get_mempolicy (x86-64)
+    return rc, mode.value, list(mask)
+
+
+def test_pinned_staging_leaves_the_callers_memory_policy_alone(srcnn):
+    """the NUMA placement of page-locked staging used to end with set_mempolicy(MPOL_DEFAULT) on the calling
+    (application) thread.  Now: whatever policy the thread had -- here MPOL_INTERLEAVE over node 0, as numactl --interleave
+    would set -- is still there after srcnn_host_alloc_pinned and after a banded ProcessSRCNN (which grows its staging)."""
+    S = srcnn
+    libc = C.CDLL(None, use_errno=True)
+    rc, mode0, mask0 = _mempolicy()
+    if rc != 0:
+        pytest.skip("get_mempolicy unavailable here")
+    node_mask = (C.c_ulong * 16)()
+    node_mask[0] = 1
+    if libc.syscall(238, 3, node_mask, C.c_ulong(1024)) != 0:                              # SYS_set_mempolicy, MPOL_INTERLEAVE
+        pytest.skip("set_mempolicy(MPOL_INTERLEAVE) refused here")
+    try:
+        before = _mempolicy()
+        assert before[1] == 3
+        p = S.lib().srcnn_host_alloc_pinned(1 << 20)
+        assert p
+        S.lib().srcnn_host_free_pinned(p)
+        assert _mempolicy() == before
+        S.lib().srcnn_trim()                                  # staging given back: the next banded call allocates it afresh
+        img = np.random.default_rng(1).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+        S.process_u8(img, 2.0)
+        assert _mempolicy() == before
+    finally:
+        libc.syscall(238, mode0, None, C.c_ulong(0))

@@ -32,6 +32,7 @@ def main():
     S.ConfigureFilterSRCNN(S.SRCNNF_Bicubic, False)
     fn = getattr(L, S.CXX_SYMBOLS[1])
     ts, cs = [], []
+    S.profile_reset(); S.profile_enable(True)
     for _ in range(args.reps + 1):
         o, osz = C.c_void_p(), C.c_uint(0)
         c0 = time.process_time(); t0 = time.perf_counter()
@@ -39,8 +40,16 @@ def main():
         ts.append(time.perf_counter() - t0); cs.append(time.process_time() - c0)
         assert rc == 0, L.srcnn_last_error()
         L.srcnn_delete_array(o)
+    S.profile_enable(False)
+    # device milliseconds per call and context (layer kernels + resampler, from the library's own events): a straggler --
+    # a slow device, a share that fills its rounds badly -- shows as the odd one out
+    per_ctx = []
+    for k in range(n):
+        pr = S.profile_read_context(k)
+        per_ctx.append(round(sum(v[0] for v in pr.values()) / (args.reps + 1), 3))
     out["process_srcnn_4k_rgb_ms"] = {"best": round(min(ts[1:]) * 1e3, 2), "all": [round(t * 1e3, 2) for t in ts[1:]],
-                                      "host_cpu_ms": round(sorted(cs[1:])[len(cs[1:]) // 2] * 1e3, 2)}
+                                      "host_cpu_ms": round(sorted(cs[1:])[len(cs[1:]) // 2] * 1e3, 2),
+                                      "device_ms_per_call_per_context": per_ctx}
     # (2) one 7680x4320 frame -> 15360x8640, tiled over the contexts vs the whole-frame call on context 0
     w, h = 7680, 4320
     y = synth.plane(h, w, synth.SEED0, "smooth")
