@@ -594,11 +594,14 @@ def dry_run_line(args, rank, world, dist):
 
 def traffic_record():
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc cannot run inside
-    this process), with where it came from.  The profile records the sha256 of the kernel's source text; if the kernel in
-    this tree is a different text, the figure is withheld (null) and the reason is given instead of a stale number."""
+    this process), with where it came from.  The profile records a sha256 over everything that decides the kernel's traffic
+    (its text, its tile / LDS constants, the LDS-DMA primitive, its launchers: build.kernel_source_sha); if that differs in
+    this tree, the figure is withheld (null) and the reason is given instead of a stale number.  Third value: the whole
+    strict path's traffic per frame (all three kernels, same passes) against the algorithmic 5 B/px, or None -- each kernel's
+    figure is held to its own fingerprint."""
     from libsrcnn_amd import build as _b
     now = _b.kernel_source_sha("k_conv12_mfma")
-    for name in ("r03_pmc_conv12.json", "r02_pmc_conv12.json", "pmc_conv12.json"):
+    for name in ("r04_pmc_conv12.json", "r03_pmc_conv12.json", "r02_pmc_conv12.json", "pmc_conv12.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -608,11 +611,18 @@ def traffic_record():
             src = "profiles/%s (%s)" % (name, rec.get("measured_at", "round 1, commit e142cbb"))
             then = rec.get("kernel_source_sha256")
             if then is None:
-                return None, src + " -- WITHHELD: that profile does not say which kernel text it measured"
+                return None, src + " -- WITHHELD: that profile does not say which kernel text it measured", None
             if then != now:
-                return None, src + " -- WITHHELD: k_conv12_mfma has changed since (re-run tools/collect_profiles.sh)"
-            return rec.get("hbm_bytes_per_launch"), src
-    return None, None
+                return None, src + " -- WITHHELD: k_conv12_mfma (text, tile constants, staging primitive or launch geometry) has changed since (re-run tools/collect_profiles.sh)", None
+            whole = None
+            wp, parts = rec.get("whole_path"), rec.get("path", {})
+            if wp and parts and all(v.get("kernel_source_sha256") == _b.kernel_source_sha(k) for k, v in parts.items()):
+                whole = {"hbm_bytes_per_frame": wp["hbm_bytes_per_frame"], "algorithmic_bytes_per_frame": wp["algorithmic_bytes_per_frame"],
+                         "ratio": round(wp["ratio"], 2),
+                         "per_kernel_GB": {k: round((v["fetch_bytes"] + v["write_bytes"]) / 1e9, 3) for k, v in parts.items()},
+                         "from": src}
+            return rec.get("hbm_bytes_per_launch"), src, whole
+    return None, None, None
 
 
 def main():
@@ -720,7 +730,7 @@ def main():
         avg12 = c12_ms / max(c12_n, 1)
         flops12 = 2.0 * MAC_L12 * n_out                         # algorithmic FLOPs of one conv12 launch (one frame)
         achieved = flops12 / (avg12 * 1e-3) / 1e12 if avg12 > 0 else 0.0
-        traffic, traffic_from = traffic_record()
+        traffic, traffic_from, whole_traffic = traffic_record()
         stage = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
         alg_bytes12 = (4 + 128) * n_out                         # layer-1+2 kernel: fp32 Y in, 32 fp32 planes out
         out = {
@@ -748,7 +758,10 @@ def main():
                                  "frac": round(alg_bytes12 / (avg12 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if avg12 > 0 else 0.0}},
             "stage_avg_ms_per_frame": stage,
             "whole_path": {"tflops": round(2.0 * MAC_ALL * mpix_step * 1e6 / (ms_per_step * 1e-3) / 1e12, 3),
-                           "hbm_algorithmic_GBps": round(5 * mpix_step * 1e6 / (ms_per_step * 1e-3) / 1e9, 2)},
+                           "hbm_algorithmic_GBps": round(5 * mpix_step * 1e6 / (ms_per_step * 1e-3) / 1e9, 2),
+                           # all kernels of the strict path, PMC FETCH+WRITE per 4K -> 8K frame vs the algorithmic 5 B/px: the 32 layer-2
+                           # planes go through HBM once between the two layer kernels (neither is bandwidth-bound: DESIGN 4.5)
+                           "hbm_traffic": whole_traffic},
             "max_abs_dY_vs_cpu_ref": None,
             "device": S.device_name(),
         }

@@ -60,9 +60,22 @@ def stale():
         return True
 
 
+def _region(src, start_pat, end_pat):
+    import re
+    m = re.search(start_pat, src)
+    if not m:
+        return None
+    e = re.search(end_pat, src[m.end():])
+    return src[m.start():m.end() + (e.start() if e else len(src) - m.end())]
+
+
 def kernel_source_sha(name="k_conv12_mfma"):
-    """sha256 of the source text of one kernel (from its template header to the next banner comment): profiles that quote a
-    counter for that kernel record it, and bench.py refuses to quote a counter taken from a different kernel text."""
+    """sha256 of everything that decides what one launch of a kernel moves through HBM: profiles that quote a counter for
+    that kernel record it, and bench.py refuses to quote a counter taken from a different text.  Covered: the kernel's body
+    (from its template header to the next banner comment) and, for the layer kernels, the constants its tile and LDS geometry
+    are built from (M_* / m_* for k_conv12_mfma, C3_* for k_conv3), the LDS-DMA primitive rs_dma_dword they stage through, the
+    launchers that set grid, block and dynamic LDS (launch_v / launch_conv12_mfma / conv12_grid_info, launch_conv3) and the
+    host function that picks the variant (run_conv12 in srcnn_capi.cpp)."""
     import hashlib
     import re
     src = open(os.path.join(CSRC, "srcnn_kernels.hip")).read()
@@ -70,7 +83,26 @@ def kernel_source_sha(name="k_conv12_mfma"):
     if not m:
         return None
     end = src.find("// ====", m.end())
-    return hashlib.sha256(src[m.start():end if end > 0 else len(src)].encode()).hexdigest()
+    parts = [src[m.start():end if end > 0 else len(src)]]
+    extra = []
+    if name == "k_conv12_mfma":
+        extra = [_region(src, r"constexpr int M_TW\b", r"\n// One tap-step"),
+                 _region(src, r"__device__ __forceinline__ void rs_dma_dword\(", r"\n}\n"),
+                 _region(src, r"template <int NW, int PIPE, int WPS, bool LD>\nstatic void launch_v\(", r"\n}\n"),
+                 _region(src, r"void conv12_grid_info\(", r"\n}\n"),
+                 _region(src, r"void launch_conv12_mfma\(", r"\n}\n"),
+                 _region(open(os.path.join(CSRC, "srcnn_capi.cpp")).read(), r"void run_conv12\(", r"\n}\n")]
+    elif name == "k_conv3":
+        extra = [_region(src, r"constexpr int C3_TW\b", r"\ntemplate <bool STRICT"),
+                 _region(src, r"__device__ __forceinline__ void rs_dma_dword\(", r"\n}\n"),
+                 _region(src, r"void launch_conv3\(", r"\n}\n")]
+    if any(e is None for e in extra):
+        return None                      # a region moved: better no fingerprint than a partial one
+    h = hashlib.sha256()
+    for part in parts + extra:
+        h.update(part.encode())
+        h.update(b"\0")
+    return h.hexdigest()
 
 
 def build(force=False, verbose=True):

@@ -620,7 +620,17 @@ void run_conv12(const Call& c, const float* Y, int W, int H, int y_row_base, int
         unsigned long long* clk = nullptr;
         if (G.clock_probe.load(std::memory_order_relaxed) && c.cx->clock_buf)
             clk = c.cx->clock_buf + 2 * (size_t)(c.cx->clock_n.fetch_add(1) % kClockSlots);
-        launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.relax(), c.cx->num_cus, G.conv12_variant, c.s, clk);
+        // the tile queue lives with the workspace: one per stream, so launches that share it are ordered
+        unsigned* queue = nullptr;
+        if (c.ws) {
+            if (!c.ws->queue && !c.ws->frozen) {
+                void* q = nullptr;
+                if (hipMalloc(&q, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(q, 0, 2 * sizeof(unsigned)) == hipSuccess) c.ws->queue = static_cast<unsigned*>(q);
+                else { (void)hipFree(q); (void)hipGetLastError(); }
+            }
+            queue = c.ws->queue;
+        }
+        launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.relax(), c.cx->num_cus, G.conv12_variant, c.s, clk, queue);
     }
 }
 
@@ -657,19 +667,28 @@ int resample_src_rows(Call& c, const YSource& src, unsigned sw, unsigned sh, uns
     if (dw <= sw) {
         // horizontal first over all source rows, then vertical (src/frawscale.cpp:195-237)
         const float* mid = d_in;
+        int mid_row_base = 0;
         if (sw != dw) {
             if ((rc = get_table(c, filter, dw, sw, th))) return rc;
             if (sh != dh) {
-                if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)dw * sh))) return rc;
-                launch_resample_rows(d_in, sw, ws.tmp, dw, sh, view_of(th), s);
+                // only the source rows the vertical taps of rows [r0, r1) read (a banded call used to redo the pass over ALL
+                // source rows for every band -- and over rows of a split plane that had not been staged yet)
+                if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
+                unsigned lo = 0, hi = sh;
+                tv->source_span(r0, r1, lo, hi);
+                hi = std::min(hi, sh);
+                if (hi <= lo) return fail(SRCNN_E_UNSUPPORTED, "empty source span for rows [%u,%u)", r0, r1);
+                if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)dw * (hi - lo)))) return rc;
+                launch_resample_rows(d_in + (size_t)lo * sw, sw, ws.tmp, dw, hi - lo, view_of(th), s);
                 mid = ws.tmp;
+                mid_row_base = (int)lo;
             } else {
                 launch_resample_rows(d_in + (size_t)r0 * sw, sw, d_dst, dw, r1 - r0, view_of(th), s);
                 return SRCNN_OK;
             }
         }
-        if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
-        launch_resample_cols(mid, dw, 0, d_dst, r0, r1 - r0, view_of(tv), s);
+        if (!tv && (rc = get_table(c, filter, dh, sh, tv))) return rc;
+        launch_resample_cols(mid, dw, mid_row_base, d_dst, r0, r1 - r0, view_of(tv), s);
     } else {
         // vertical first, then horizontal (src/frawscale.cpp:238-278)
         if (!th && (rc = get_table(c, filter, dw, sw, th))) return rc;

@@ -69,12 +69,13 @@ struct Workspace {          // scratch of one stream / graph / lane; grow-only
     float* c2 = nullptr;    size_t c2_n = 0;     // 32 layer-2 planes (band)
     float* planes = nullptr; size_t planes_n = 0; // colour shell: split planes / Y' / resized chroma planes
     unsigned char* bytes = nullptr; size_t bytes_n = 0;
+    unsigned* queue = nullptr;                   // two words: the tile queue of k_conv12_mfma launches on this workspace's stream
     bool frozen = false;    // a captured graph has these pointers baked in: growing is an error
     size_t footprint() const { return sizeof(float) * (tmp_n + up_n + c2_n + planes_n) + bytes_n; }
     void release()
     {
-        (void)hipFree(tmp); (void)hipFree(up); (void)hipFree(c2); (void)hipFree(planes); (void)hipFree(bytes);
-        tmp = up = c2 = planes = nullptr; bytes = nullptr;
+        (void)hipFree(tmp); (void)hipFree(up); (void)hipFree(c2); (void)hipFree(planes); (void)hipFree(bytes); (void)hipFree(queue);
+        tmp = up = c2 = planes = nullptr; bytes = nullptr; queue = nullptr;
         tmp_n = up_n = c2_n = planes_n = bytes_n = 0;
     }
 };

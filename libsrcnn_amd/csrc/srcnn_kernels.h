@@ -114,8 +114,11 @@ void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, flo
 hipError_t conv12_mfma_prepare();
 // relax: RELAX_L1 | RELAX_L2 bits (0 = strict); the single-layer forms always take the production geometry (variant 1)
 // clk: NULL, or two device words that receive (shader-clock cycles, 100 MHz ticks) of workgroup 0's lifetime
+// queue: NULL (tiles dealt with a static stride), or two zeroed device words owned by the launch stream's workspace: the tile
+//        queue of the production kernel (it leaves them zeroed again); SRCNN_CONV12_QUEUE=0 ignores it (A/B runs)
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                        int out_rows, int relax, int num_cus, int variant, hipStream_t s, unsigned long long* clk = nullptr);
+                        int out_rows, int relax, int num_cus, int variant, hipStream_t s, unsigned long long* clk = nullptr,
+                        unsigned* queue = nullptr);
 void conv12_grid_info(int num_cus, int variant, int* blocks, int* tile_rows);
 hipError_t conv12_f16_prepare();
 void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,

@@ -795,7 +795,7 @@ constexpr int M_C1 = 32 * 32;                      // per-wave layer-1 slab: 32 
 constexpr int m_th(int nw) { return 2 * nw; }
 constexpr int m_yt(int nw) { return (m_th(nw) + 8) * M_LW; }
 constexpr int m_ybufs(bool ld) { return ld ? 2 : 1; }          // LDS-DMA staging double-buffers the Y tile
-constexpr int m_lds_floats(int nw, bool ld) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(ld) * m_yt(nw) + nw * M_C1; }
+constexpr int m_lds_floats(int nw, bool ld) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(ld) * m_yt(nw) + nw * M_C1 + 2; }   // + the two tile-queue slots
 
 // One tap-step of the product/accumulate pipeline.  PIPE=1: the MFMA of step t+1 is issued, then the VALU
 // folds in the result of step t (two result buffers).  PIPE=0: one buffer, the adds wait for their own
@@ -809,7 +809,7 @@ template <int RELAX, int NW, int PIPE, int WPS, bool LD = false>
 __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
     const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles,
-    unsigned long long* __restrict__ clk)
+    unsigned long long* __restrict__ clk, unsigned* __restrict__ queue)
 {
     constexpr int NT = 64 * NW, TH = m_th(NW), YT = m_yt(NW);
     // clk != NULL (srcnn_debug_clock_probe): workgroup 0 -- resident from the first round to the last -- stamps the shader
@@ -903,19 +903,38 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
             }
         }
     };
+    // Which item next?  Static stride (queue == NULL): item + gridDim.x.  Tile QUEUE (the production form with LDS-DMA staging):
+    // a workgroup's first item is its own index, every further one comes from a global counter (index = gridDim.x + old value).
+    // Why: the SIMDs issue oldest-wave-first, so of the two workgroups that share a CU the one that arrived first runs ahead
+    // -- measured, it finishes its static half of the tiles after 4.1 ms of a 7.3 ms launch (profiles/r04_process_clock.txt) --
+    // and the rest of the launch runs at two waves per SIMD instead of four.  With the queue both keep drawing tiles until
+    // none are left.  The index is needed one item AHEAD (the next tile's DMA is issued at the top of the current item):
+    // lane 0 draws it an item early and passes it through a two-slot LDS mailbox that the item's one barrier publishes.
+    // The counters clean up after themselves: the last workgroup to leave puts both back to zero (queue[1] counts leavers),
+    // so a workspace's queue needs no memset between the launches of its stream.
+    int* qslot = reinterpret_cast<int*>(C1s + NW * M_C1);
+    const bool dyn = DMA && queue != nullptr;
     int it = 0;
-    if constexpr (DMA) { if ((int)blockIdx.x < nitems) request(blockIdx.x, Yt); }
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++it) {
+    int item = blockIdx.x;
+    if constexpr (DMA) {
+        if (item < nitems) request(item, Yt);
+        if (dyn && tid == 0 && item < nitems) qslot[0] = (int)gridDim.x + (int)atomicAdd(queue, 1u);
+    }
+    for (; item < nitems; ++it) {
         int s0, s1;
         const int tile = tile_of(item, s0, s1);
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
         const int tx0 = txi * M_TW, ty0 = out_row0 + tyi * TH;
         const float* Ytc = Yt;
+        int next_item = item + (int)gridDim.x;
+        int drawn = 0x7fffffff;
         if constexpr (DMA) {
             Ytc = Yt + (it & 1) * YT;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the item's tile has landed
             __syncthreads();                                    // ... everybody's has; the previous item is finished everywhere
-            if (item + (int)gridDim.x < nitems) request(item + gridDim.x, Yt + ((it + 1) & 1) * YT);
+            if (dyn) next_item = __builtin_amdgcn_readfirstlane(qslot[it & 1]);
+            if (next_item < nitems) request(next_item, Yt + ((it + 1) & 1) * YT);
+            if (dyn && tid == 0 && next_item < nitems) drawn = (int)gridDim.x + (int)atomicAdd(queue, 1u);     // the item after next
         } else {
             __syncthreads();
             for (int e = tid; e < YT; e += NT) {
@@ -1058,6 +1077,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
                 }
             }
         }
+        if (dyn && tid == 0) qslot[(it + 1) & 1] = drawn;        // read by everybody after the next item's barrier
+        item = next_item;
+    }
+    if (dyn && tid == 0) {
+        // every draw of this workgroup has returned (its value went through the mailbox); the last one out resets the queue
+        if (atomicAdd(queue + 1, 1u) == gridDim.x - 1) { queue[0] = 0u; queue[1] = 0u; }
     }
     if (clk && blockIdx.x == 0) {
         __syncthreads();
@@ -1889,7 +1914,7 @@ void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows,
 
 template <int NW, int PIPE, int WPS, bool LD>
 static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                     int out_rows, int relax, int num_cus, int blocks_per_cu, hipStream_t s, unsigned long long* clk)
+                     int out_rows, int relax, int num_cus, int blocks_per_cu, hipStream_t s, unsigned long long* clk, unsigned* queue)
 {
     const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, m_th(NW));
     const int ntiles = tiles_x * tiles_y;
@@ -1900,7 +1925,7 @@ static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, f
     const int grid = ntiles >= cap ? cap : (spread ? std::min(4 * ntiles, cap) : ntiles);
     const size_t lds = sizeof(float) * m_lds_floats(NW, LD);
 #define CONV12_GO(R) hipLaunchKernelGGL((k_conv12_mfma<R, NW, PIPE, WPS, LD>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, \
-                                       y_rows, C2, plane_stride, out_row0, out_rows, tiles_x, ntiles, clk)
+                                       y_rows, C2, plane_stride, out_row0, out_rows, tiles_x, ntiles, clk, LD ? queue : nullptr)
     relax &= 3;
     if (relax == 0) CONV12_GO(0);
     else if (relax == 3) CONV12_GO(3);
@@ -1925,16 +1950,18 @@ void conv12_grid_info(int num_cus, int variant, int* blocks, int* tile_rows)
 }
 
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                        int out_rows, int relax, int num_cus, int variant, hipStream_t s, unsigned long long* clk)
+                        int out_rows, int relax, int num_cus, int variant, hipStream_t s, unsigned long long* clk, unsigned* queue)
 {
     if (out_rows <= 0) return;
+    static const bool dyn = [] { const char* e = getenv("SRCNN_CONV12_QUEUE"); return !(e && e[0] == '0'); }();     // A/B: 0 = static stride
+    if (!dyn) queue = nullptr;
     if ((relax & 3) == 1 || (relax & 3) == 2) variant = 1;
     switch (variant) {
-    case 0: launch_v<4, 1, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 3, s, clk); break;
-    default: launch_v<8, 0, 4, true>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 2, s, clk); break;
-    case 2: launch_v<4, 0, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 3, s, clk); break;
-    case 3: launch_v<8, 1, 2, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 1, s, clk); break;
-    case 4: launch_v<8, 0, 4, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 2, s, clk); break;
+    case 0: launch_v<4, 1, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 3, s, clk, queue); break;
+    default: launch_v<8, 0, 4, true>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 2, s, clk, queue); break;
+    case 2: launch_v<4, 0, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 3, s, clk, queue); break;
+    case 3: launch_v<8, 1, 2, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 1, s, clk, queue); break;
+    case 4: launch_v<8, 0, 4, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 2, s, clk, queue); break;
     }
 }
 

@@ -34,6 +34,53 @@ def have_reference():
     return os.path.exists(REF_SO)
 
 
+# ---- OpenMP team size ----------------------------------------------------------------------------
+# Both libraries parallelise with `#pragma omp parallel for` and, left alone, start one thread per LOGICAL cpu of the host --
+# 256 on the GPU boxes, whose containers may own far fewer cores.  For the small planes most tests check, a team that large
+# spends its time spinning at barriers (a 130 x 130 case took ~1 s on the GPU box and 0.05 s on 8 cores): the team is
+# therefore sized per call -- by the work, capped by the cpus this process may actually use and by 64 (layer 1 has 64
+# parallel iterations, src/libsrcnn.cpp:791).  An explicit OMP_NUM_THREADS in the environment is left alone (bench.py's
+# cpu_baseline sets it as SURVEY 8d asks).  Results do not depend on the team size (every reduction is per sample).
+def cpu_budget():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:                                         # cgroup v2 quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:                                     # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+_gomp = None
+_BUDGET = None
+
+
+def set_team(pixels):
+    """Size the OpenMP team of the calling thread for a call that produces `pixels` output samples."""
+    global _gomp, _BUDGET
+    if os.environ.get("OMP_NUM_THREADS"):
+        return
+    if _gomp is None:
+        try:
+            _gomp = C.CDLL("libgomp.so.1")
+            _gomp.omp_set_num_threads.argtypes = [C.c_int]
+        except OSError:
+            _gomp = False
+        _BUDGET = min(cpu_budget(), 64)
+    if _gomp:
+        _gomp.omp_set_num_threads(int(max(1, min(_BUDGET, pixels // 1024))))
+
+
 class _Stages:
     """Stage-level calls shared by the restatement (prefix 'oracle_') and the reference ('ref_')."""
 
@@ -66,6 +113,7 @@ class _Stages:
         plane = np.ascontiguousarray(plane, np.float32)
         h, w = plane.shape
         out = np.zeros((dh, dw), np.float32)
+        set_team(dw * dh)
         rc = self._resample(plane, w, h, dw, dh, out, filt)
         if rc != 0:
             raise RuntimeError("resample failed rc=%d" % rc)
@@ -75,6 +123,7 @@ class _Stages:
         y = np.ascontiguousarray(y, np.float32)
         h, w = y.shape
         out = np.empty((64, h, w), np.float32)
+        set_team(w * h)
         self._conv1(y, w, h, out)
         return out
 
@@ -82,6 +131,7 @@ class _Stages:
         c1 = np.ascontiguousarray(c1, np.float32)
         _, h, w = c1.shape
         out = np.empty((32, h, w), np.float32)
+        set_team(w * h)
         self._conv2(c1, w, h, out)
         return out
 
@@ -89,6 +139,7 @@ class _Stages:
         c2 = np.ascontiguousarray(c2, np.float32)
         _, h, w = c2.shape
         out = np.empty((h, w), np.float32)
+        set_team(w * h)
         self._conv3(c2, w, h, out)
         return out
 
@@ -100,6 +151,7 @@ class _Stages:
         dw = 2 * w if dw is None else dw
         dh = 2 * h if dh is None else dh
         out = np.empty((dh, dw), np.float32)
+        set_team(dw * dh)
         if taps:
             up = np.zeros((dh, dw), np.float32)
             c1 = np.empty((64, dh, dw), np.float32)
@@ -133,6 +185,7 @@ class Oracle(_Stages):
         dw, dh = int(np.float32(w) * mulf), int(np.float32(h) * mulf)
         out = np.empty((dh, dw, d), np.uint8)
         conv = np.empty((dh, dw), np.uint8)
+        set_team(dw * dh)
         rc = self.lib.oracle_dosrcnn(rgb, w, h, d, float(mulf), filt, out, conv.ctypes.data)
         if rc != 0:
             raise RuntimeError("oracle_dosrcnn rc=%d" % rc)
@@ -166,6 +219,7 @@ class Reference(_Stages):
         out = np.empty((dh, dw, d), np.uint8)
         conv = np.empty((dh, dw), np.uint8)
         osz, csz = C.c_uint(0), C.c_uint(0)
+        set_team(dw * dh)
         rc = self.lib.ref_process(rgb, w, h, d, float(mulf), filt, int(step), out, out.size, C.byref(osz),
                                   conv.ctypes.data, conv.size, C.byref(csz))
         if rc != 0:

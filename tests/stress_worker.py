@@ -4,7 +4,7 @@ thousands of times over random shapes 1..130, every result compared bit for bit 
 that the kernel selection comes from the environment (SRCNN_CONV12_VARIANT, SRCNN_CONV3_WDMA, SRCNN_CONV12_SPREAD ...) and
 so that a runtime abort leaves its stderr in a file instead of in pytest's capture buffer.  Test infrastructure: uses oracle/.
 
-    python tests/stress_worker.py ITERATIONS SEED [POOL]      -> one JSON line; exit code 1 on any mismatch"""
+    python tests/stress_worker.py ITERATIONS SEED [POOL [POOL_FILE]]      -> one JSON line; exit code 1 on any mismatch"""
 import ctypes as C
 import json
 import os
@@ -21,13 +21,11 @@ from libsrcnn_amd import synth     # noqa: E402
 import oracle                      # noqa: E402
 
 
-def main(iters, seed, pool_n):
-    rng = np.random.default_rng(seed)
-    S.init(0)
-    L = S.lib()
+def make_pool(pool_n, seed):
+    """pool_n float cases (plane, the oracle's layer-2 planes, the oracle's result) and pool_n // 8 small images with the
+    oracle's ProcessSRCNN bytes."""
+    rng = np.random.default_rng([seed, 77])
     orc = oracle.Oracle()
-    t0 = time.time()
-    # ---- a pool of cases with their oracle answers (the oracle is the slow part: computed once per case) ----
     pool = []
     for k in range(pool_n):
         h, w = int(rng.integers(1, 131)), int(rng.integers(1, 131))
@@ -36,16 +34,40 @@ def main(iters, seed, pool_n):
         y = synth.plane(h, w, int(rng.integers(0, 1 << 30)), "noise" if k % 2 else "smooth")
         if k % 11 == 10:
             y *= np.float32(rng.choice([0.0, 1e-3, 4.0, -1.0]))
-        up = orc.resample(y, 2 * w, 2 * h)
-        c1 = orc.conv1(up)
-        c2 = orc.conv2(c1)
-        out = orc.conv3(c2)
+        out, _, _, c2 = orc.y_path(y, taps=True)
         pool.append({"y": y, "c2": np.ascontiguousarray(c2), "out": out})
     imgs = []
     for k in range(max(4, pool_n // 8)):
         h, w, d = int(rng.integers(1, 100)), int(rng.integers(1, 130)), int(rng.choice([3, 4]))
         img = rng.integers(0, 256, (h, w, d), dtype=np.uint8)
         imgs.append((img,) + tuple(orc.process(img, 2.0)))
+    return pool, imgs
+
+
+def save_pool(path, pool_n, seed):
+    pool, imgs = make_pool(pool_n, seed)
+    d = {"n": len(pool), "ni": len(imgs)}
+    for k, p in enumerate(pool):
+        d["y%d" % k] = p["y"]; d["c2_%d" % k] = p["c2"]; d["out%d" % k] = p["out"]
+    for k, (img, rgb, conv) in enumerate(imgs):
+        d["img%d" % k] = img; d["rgb%d" % k] = rgb; d["conv%d" % k] = conv
+    np.savez(path, **d)
+
+
+def main(iters, seed, pool_n, pool_file=None):
+    rng = np.random.default_rng(seed)
+    S.init(0)
+    L = S.lib()
+    t0 = time.time()
+    # ---- a pool of cases with their oracle answers (the oracle is the slow part: the parent test computes the pool once,
+    #      with make_pool() below, and hands the file to every child) ----
+    if pool_file and os.path.exists(pool_file):
+        z = np.load(pool_file)
+        n = int(z["n"]); ni = int(z["ni"])
+        pool = [{"y": z["y%d" % k], "c2": z["c2_%d" % k], "out": z["out%d" % k]} for k in range(n)]
+        imgs = [(z["img%d" % k], z["rgb%d" % k], z["conv%d" % k]) for k in range(ni)]
+    else:
+        pool, imgs = make_pool(pool_n, seed)
     t_pool = time.time() - t0
 
     # ---- device buffers sized for the largest case, reused (no allocation inside the loop) ----
@@ -113,4 +135,4 @@ def main(iters, seed, pool_n):
 
 if __name__ == "__main__":
     sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 2000, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
-                  int(sys.argv[3]) if len(sys.argv) > 3 else 48))
+                  int(sys.argv[3]) if len(sys.argv) > 3 else 48, sys.argv[4] if len(sys.argv) > 4 else None))

@@ -45,15 +45,15 @@ def test_traffic_is_withheld_for_a_different_kernel_text(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     rec = {"hbm_bytes_per_launch": 123.0, "measured_at": "test", "kernel_source_sha256": b.kernel_source_sha("k_conv12_mfma")}
     (prof / "r03_pmc_conv12.json").write_text(json.dumps(rec))
-    val, src = bench.traffic_record()
+    val, src, _whole = bench.traffic_record()
     assert val == 123.0 and "r03_pmc_conv12.json" in src
     rec["kernel_source_sha256"] = "f" * 64
     (prof / "r03_pmc_conv12.json").write_text(json.dumps(rec))
-    val, src = bench.traffic_record()
+    val, src, _whole = bench.traffic_record()
     assert val is None and "WITHHELD" in src
     del rec["kernel_source_sha256"]
     (prof / "r03_pmc_conv12.json").write_text(json.dumps(rec))
-    val, src = bench.traffic_record()
+    val, src, _whole = bench.traffic_record()
     assert val is None and "WITHHELD" in src
 
 

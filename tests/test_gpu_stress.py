@@ -17,15 +17,26 @@ WORKER = os.path.join(ROOT, "tests", "stress_worker.py")
 OUT = os.path.join(ROOT, "gpurun_out")
 
 CASES = [
-    ("dma-default", {}, 2000),
-    ("dma-no-quarter-spread", {"SRCNN_CONV12_SPREAD": "0"}, 700),
-    ("no-dma-variant4", {"SRCNN_CONV12_VARIANT": "4", "SRCNN_CONV3_WDMA": "0"}, 2000),
+    ("dma-default", {}, 12000),
+    ("dma-no-quarter-spread", {"SRCNN_CONV12_SPREAD": "0"}, 4000),
+    ("no-dma-variant4", {"SRCNN_CONV12_VARIANT": "4", "SRCNN_CONV3_WDMA": "0"}, 4000),
 ]
+SEED = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(time.time()) & 0xFFFFF)
+
+
+@pytest.fixture(scope="module")
+def pool_file(tmp_path_factory):
+    """The cases and their oracle answers, computed ONCE (the oracle is the slow part) and shared by the children."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stress_worker
+    path = str(tmp_path_factory.mktemp("stress") / "pool.npz")
+    stress_worker.save_pool(path, 40, SEED)
+    return path
 
 
 @pytest.mark.parametrize("name,env,iters", CASES, ids=[c[0] for c in CASES])
-def test_small_shape_launches_interleaved_with_h2d_copies(name, env, iters):
-    seed = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(time.time()) & 0xFFFFF)
+def test_small_shape_launches_interleaved_with_h2d_copies(name, env, iters, pool_file):
+    seed = SEED
     e = dict(os.environ)
     e.pop("SRCNN_DEVICES", None)
     e.update(env)
@@ -33,8 +44,8 @@ def test_small_shape_launches_interleaved_with_h2d_copies(name, env, iters):
     os.makedirs(OUT, exist_ok=True)
     err_path = os.path.join(OUT, "stress_%s.err" % name)
     with open(err_path, "w") as err:
-        r = subprocess.run([sys.executable, WORKER, str(iters), str(seed)], env=e, stdout=subprocess.PIPE, stderr=err,
-                           text=True, timeout=600)
+        r = subprocess.run([sys.executable, WORKER, str(iters), str(seed), "40", pool_file], env=e, stdout=subprocess.PIPE,
+                           stderr=err, text=True, timeout=600)
     tail = open(err_path).read()[-3000:]
     assert r.returncode == 0, "stress '%s' seed %d: exit %d\nstdout: %s\nstderr tail (kept in %s):\n%s" % (
         name, seed, r.returncode, r.stdout[-1000:], err_path, tail)

@@ -34,6 +34,11 @@ def short(name):
         tier = " [strict]"
     elif "<false" in name:
         tier = " [fast tier]"
+    if "k_conv12_mfma<" in name:          # first template argument = RELAX mask: 0 strict, 3 fast tier, 1 / 2 single-layer relaxations
+        r = name.split("k_conv12_mfma<")[1].split(",")[0].strip()
+        return "k_conv12_mfma" + {"0": " [strict]", "3": " [fast tier]"}.get(r, " [relaxed %s]" % r)
+    if "k_conv3<" in name and name.split("k_conv3<")[1].split(">")[0].replace(" ", "").endswith(",true"):
+        return "k_conv3 [relaxed x64]"
     if "k_rs2d_dma" in name:
         return "k_rs2d_dma [plane -> plane, LDS-DMA]"
     if "k_rs2d<" in name:
@@ -89,6 +94,22 @@ if pmc:
                        "our loads are 4 B/lane, calibrated on k_conv3 of the same run: it requests 5.65 GB (4.25 GB of unique "
                        "layer-2 planes x 1.33 halo) and FETCH_SIZE reads 4.73 GB -- a halved counter would imply 9.5 GB, more "
                        "than was requested -- so FETCH_SIZE is taken at face value.  WRITE_SIZE matches 128 B/px exactly."}
+        # the other kernels of the strict path, same passes: what one 4K -> 8K frame moves through HBM in total
+        path = {"k_conv12_mfma": {"fetch_bytes": fetch, "write_bytes": write, "kernel_source_sha256": rec["kernel_source_sha256"]}}
+        for kname, key in (("k_conv3", "k_conv3 [strict]"), ("k_rs2d_dma", "k_rs2d_dma [plane -> plane, LDS-DMA]")):
+            kk = pmc.get(key)
+            if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
+                path[kname] = {"fetch_bytes": kk["FETCH_SIZE"] * 1024, "write_bytes": kk["WRITE_SIZE"] * 1024,
+                               "kernel_source_sha256": _b.kernel_source_sha(kname)}
+        rec["path"] = path
+        if len(path) == 3:
+            total = sum(v["fetch_bytes"] + v["write_bytes"] for v in path.values())
+            rec["whole_path"] = {"hbm_bytes_per_frame": total, "algorithmic_bytes_per_frame": 5 * n_out,
+                                 "ratio": total / (5 * n_out),
+                                 "note": "algorithmic = 1 B of low-res input + 4 B of output per output pixel (SURVEY 8d, upscale fused); the "
+                                         "excess is the 32 layer-2 planes making one round trip through HBM between k_conv12_mfma and k_conv3"}
+            lines.append("\nwhole strict path per frame: %.3f GB through HBM vs %.3f GB algorithmic (5 B/px) -> ratio %.1f"
+                         % (total / 1e9, 5 * n_out / 1e9, total / (5 * n_out)))
         json.dump(rec, open(os.path.join(dst, tag + "_pmc_conv12.json"), "w"), indent=1)
         lines.append("\nconv12 HBM traffic per launch = %.3f GB (fetch %.3f + write %.3f) vs algorithmic %.3f GB -> ratio %.3f"
                      % ((fetch + write) / 1e9, fetch / 1e9, write / 1e9, 132 * n_out / 1e9, (fetch + write) / (132 * n_out)))
