@@ -434,6 +434,26 @@ def process_u8(rgb, multiply=2.0, filt=SRCNNF_Bicubic, want_conv=True):
     return out, conv
 
 
+class PinnedArray:
+    """A numpy array on page-locked host memory from srcnn_host_alloc_pinned: srcnn_process_u8 / ProcessJob move such buffers
+    to and from the device without staging copies.  Keep the object alive while the array is in use; free() when done."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = lib().srcnn_host_alloc_pinned(max(1, self.nbytes))
+        if not self.ptr:
+            raise SrcnnError(-202, lib().srcnn_last_error().decode())
+        raw = (C.c_ubyte * max(1, self.nbytes)).from_address(self.ptr)
+        self.array = np.frombuffer(raw, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().srcnn_host_free_pinned(self.ptr)
+            self.ptr = None
+
+
 class ProcessJob:
     """srcnn_process_u8_begin / _wait: the image is being produced; result() blocks and returns (rgb_out, conv_y|None)."""
 

@@ -625,7 +625,9 @@ void run_conv12(const Call& c, const float* Y, int W, int H, int y_row_base, int
         if (c.ws) {
             if (!c.ws->queue && !c.ws->frozen) {
                 void* q = nullptr;
-                if (hipMalloc(&q, 2 * sizeof(unsigned)) == hipSuccess && hipMemset(q, 0, 2 * sizeof(unsigned)) == hipSuccess) c.ws->queue = static_cast<unsigned*>(q);
+                // zeroed ON THE LAUNCH STREAM: lane streams are non-blocking, so a null-stream hipMemset is not ordered before
+                // the first kernel that draws from the queue (seen as wrong tiles in the first call of a fresh lane)
+                if (hipMalloc(&q, 2 * sizeof(unsigned)) == hipSuccess && hipMemsetAsync(q, 0, 2 * sizeof(unsigned), c.s) == hipSuccess) c.ws->queue = static_cast<unsigned*>(q);
                 else { (void)hipFree(q); (void)hipGetLastError(); }
             }
             queue = c.ws->queue;
@@ -1344,7 +1346,7 @@ int srcnn_debug_clock_probe(int on)
             if (hipMalloc(&p, sizeof(unsigned long long) * 2 * kClockSlots) != hipSuccess) return fail(SRCNN_E_DEVMEM, "clock probe buffer");
             cx->clock_buf = static_cast<unsigned long long*>(p);
         }
-        if (cx->clock_buf) (void)hipMemset(cx->clock_buf, 0, sizeof(unsigned long long) * 2 * kClockSlots);
+        if (cx->clock_buf) { (void)hipMemset(cx->clock_buf, 0, sizeof(unsigned long long) * 2 * kClockSlots); (void)hipDeviceSynchronize(); }
         cx->clock_n = 0;
     }
     if (Ctx* cur = context_at(srcnn_get_context())) (void)hipSetDevice(cur->device);

@@ -225,10 +225,35 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
 // ------------------------------------------------------------------------------------------------------------------
 // ProcessSRCNN surface.
 // ------------------------------------------------------------------------------------------------------------------
+// One link of the chain that orders the KERNELS of consecutive asynchronous jobs on a device (srcnn_process_u8_begin): a job
+// records `ev` on its compute stream once its last band's kernels are queued, its successor makes its own compute stream wait
+// for `ev` before its first kernel.  The successor's stage-in copies do not wait, and the predecessor's copy-out and fan-out
+// run beside the successor's kernels: the device goes from the last kernel of one image to the first of the next without
+// idling and without two images' kernels sharing it.  `done` (under m) says the link is settled: recorded, or given up.
+struct AsyncLink {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, valid = false;
+    bool leased = false;        // the job holds its lane: lanes are taken in chain order, or later jobs could take them all and
+                                // wait for a predecessor that waits for a lane
+    hipEvent_t ev = nullptr;
+    int device = 0;
+    void settle(bool ok)
+    {
+        { std::lock_guard<std::mutex> lk(m); if (done) return; done = true; leased = true; valid = ok; }
+        cv.notify_all();
+    }
+    void mark_leased() { { std::lock_guard<std::mutex> lk(m); leased = true; } cv.notify_all(); }
+    void wait_leased() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return leased; }); }
+    ~AsyncLink() { if (ev) { (void)hipSetDevice(device); (void)hipEventDestroy(ev); } }
+};
+
 struct ProcJob {            // one srcnn_process_u8 call; shared (read-only) by its per-context workers
     const unsigned char* rgb; unsigned w, h, d, dw, dh; int filter, cfilter, mode;
     unsigned char* out; unsigned char* conv;
     bool trace;
+    AsyncLink* after = nullptr;     // asynchronous jobs: the previous job's link (kernels wait for it) ...
+    AsyncLink* mine = nullptr;      // ... and this job's own (recorded behind its last kernel)
 };
 
 // Bands of a share [R0,R1) of a (dw x dh) output: about 10 / 30 / 30 / 20 / 7 / 3 % of the rows (a share of a multi-context call:
@@ -288,7 +313,9 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     int rc = bind(cx);
     if (rc) return rc;
     TraceRange tr("srcnn_process_u8 ctx %d rows [%u,%u) of %ux%ux%u -> %ux%u", cx.index, R0, R1, J.w, J.h, J.d, J.dw, J.dh);
+    if (J.after) J.after->wait_leased();
     LaneLease lease(cx);
+    if (J.mine) J.mine->mark_leased();
     if (lease.rc) return lease.rc;
     ProcLane& L = *lease.lane;
     Workspace& ws = L.ws;
@@ -374,6 +401,12 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 
     const size_t out_bytes = share_px * d;
     const bool small = out_bytes < (8u << 20) && !one_of_many;
+    // Buffers the caller allocated page-locked (srcnn_host_alloc_pinned / hipHostMalloc) need no staging: the source rows go
+    // to the device straight from the caller's image and every band lands straight in the caller's result.  That removes the
+    // 125 MB of staging memcpy and the 100 MB fan-out per 4K image that bound a SEQUENCE of calls on the host
+    // (profiles/r04_process_clock.txt: 10.8 ms per image blocking, 11.5 with two jobs in flight, for 9 ms of device work).
+    const bool in_pinned = !small && is_pinned(J.rgb);
+    const bool out_pinned = !small && is_pinned(J.out) && (!J.conv || is_pinned(J.conv));
     // ---- stage-in.  Small images: the share's source rows in one go, straight from the caller's (pageable) buffer.  Large
     //      images: band by band -- stage_rows(upto) brings source rows [staged, upto) through the page-locked staging to the
     //      device (and, on the plane path, splits them), so the first band's kernels start after a third of the copy and the
@@ -394,9 +427,13 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
             // but on this runtime a cross-stream wait is resolved by a thread of the RUNTIME that stays busy from the call until
             // the event fires: 9.5 ms of CPU per 11.7 ms call, and no faster (tools/runtime_thread_probe.py,
             // profiles/r03_wait_cost.txt).  SRCNN_DEVICE_WAIT_IN=1 selects it for A/B runs.
-            parallel_memcpy(L.pin_in + (off - src_off), J.rgb + off, nbytes);
+            const unsigned char* from = J.rgb + off;
+            if (!in_pinned) {
+                parallel_memcpy(L.pin_in + (off - src_off), J.rgb + off, nbytes);
+                from = L.pin_in + (off - src_off);
+            }
             hipEvent_t ev = L.band_events[2 * nb + n_staged++];
-            HIP_TRY(hipMemcpyAsync(d_rgb + off, L.pin_in + (off - src_off), nbytes, hipMemcpyHostToDevice, L.in_st));
+            HIP_TRY(hipMemcpyAsync(d_rgb + off, from, nbytes, hipMemcpyHostToDevice, L.in_st));
             HIP_TRY(hipEventRecord(ev, L.in_st));
             static const bool device_wait = [] { const char* e = getenv("SRCNN_DEVICE_WAIT_IN"); return e && atoi(e) != 0; }();
             if (device_wait) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
@@ -422,21 +459,43 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     std::thread prefault;
     bool prefaulting = false;
     if (!small) {
-        if ((rc = grow_pinned(cx, L.pin_in, L.pin_in_n, src_bytes))) return rc;
-        if ((rc = grow_pinned(cx, L.pin_out, L.pin_out_n, out_bytes + share_px))) return rc;
+        if (!in_pinned && (rc = grow_pinned(cx, L.pin_in, L.pin_in_n, src_bytes))) return rc;
+        if (!out_pinned && (rc = grow_pinned(cx, L.pin_out, L.pin_out_n, out_bytes + share_px))) return rc;
         unsigned char* o0 = J.out + (size_t)R0 * dw * d;
         unsigned char* c0 = J.conv ? J.conv + (size_t)R0 * dw : nullptr;
-        hint_huge_pages(o0, out_bytes);
-        if (c0) hint_huge_pages(c0, share_px);
+        if (!out_pinned) {
+            hint_huge_pages(o0, out_bytes);
+            if (c0) hint_huge_pages(c0, share_px);
+        }
         static const bool no_prefault = [] { const char* e = getenv("SRCNN_PREFAULT"); return e && atoi(e) == 0; }();
         static const int pf_threads = [] { const char* e = getenv("SRCNN_PREFAULT_THREADS"); return e ? std::max(1, atoi(e)) : 1; }();
-        if (!no_prefault) prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes, pf_threads); if (c0) prefault_pages(c0, share_px); });
+        if (!no_prefault && !out_pinned) prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes, pf_threads); if (c0) prefault_pages(c0, share_px); });
     }
     struct JoinPrefault {                                      // whatever path leaves this function: the helper is joined first
         std::thread& t; bool& on;
         ~JoinPrefault() { if (on) t.join(); }
     } join_prefault{prefault, prefaulting};
     const auto t1 = now();
+
+    // asynchronous chain (see AsyncLink): called once, right before this job's first launch on the compute stream
+    bool chained_in = false;
+    auto chain_in = [&]() -> int {
+        if (chained_in || !J.after) return SRCNN_OK;
+        chained_in = true;
+        AsyncLink& a = *J.after;
+        std::unique_lock<std::mutex> lk(a.m);
+        a.cv.wait(lk, [&] { return a.done; });
+        if (a.valid && a.ev) HIP_TRY(hipStreamWaitEvent(s, a.ev, 0));
+        return SRCNN_OK;
+    };
+    auto chain_out = [&]() {          // right after this job's last launch on the compute stream
+        if (!J.mine) return;
+        AsyncLink& m = *J.mine;
+        m.device = cx.device;
+        bool ok = m.ev || hipEventCreateWithFlags(&m.ev, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventRecord(m.ev, s) == hipSuccess;
+        m.settle(ok);
+    };
 
     const YSource ysrc = fused_shell ? YSource::from_rgb(d_rgb, (int)d) : YSource::from_plane(sp[0]);
     auto run_band = [&](unsigned a, unsigned b) -> int {       // kernels of output rows [a,b)
@@ -460,8 +519,10 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 
     if (small) {
         // small image: one shot on the lane's stream
+        if ((rc = chain_in())) return rc;
         if ((rc = stage_rows(hi))) return rc;
         if ((rc = run_band(R0, R1))) return rc;
+        chain_out();
         HIP_TRY(hipMemcpyAsync(J.out + (size_t)R0 * dw * d, d_out, out_bytes, hipMemcpyDeviceToHost, s));
         if (J.conv) HIP_TRY(hipMemcpyAsync(J.conv + (size_t)R0 * dw, d_conv, share_px, hipMemcpyDeviceToHost, s));
         HIP_TRY(wait_stream(s));
@@ -473,8 +534,8 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     // sides, the output produced in bands (bit-identical to the whole frame, tests/test_gpu_parity.py::
     // test_bands_equal_whole_frame), each band's D2H on the copy stream while the next band computes, and a helper thread
     // that fans each landed band out to the caller's buffers.  The helper blocks on events; it never spins.
-    unsigned char* pin_rgb = L.pin_out;
-    unsigned char* pin_conv = L.pin_out + out_bytes;
+    unsigned char* pin_rgb = out_pinned ? nullptr : L.pin_out;
+    unsigned char* pin_conv = out_pinned ? nullptr : L.pin_out + out_bytes;
     std::atomic<int> copy_err{0};
     // SRCNN_TRACE stamps, microseconds since entry: first band queued, last band's kernels done, last band landed in staging
     std::atomic<long> us_first_queued{0}, us_kernels_done{0}, us_landed{0};
@@ -484,9 +545,12 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
         const hipError_t kd = wait_event(L.band_events[2 * b]);
         if (b + 1 == nb) us_kernels_done = since();
+        const size_t g0 = (size_t)cuts[b] * dw;
+        unsigned char* to_rgb = out_pinned ? J.out + g0 * d : pin_rgb + p0 * d;          // page-locked result: no staging
+        unsigned char* to_conv = out_pinned ? (J.conv ? J.conv + g0 : nullptr) : pin_conv + p0;
         if (kd != hipSuccess ||
-            hipMemcpyAsync(pin_rgb + p0 * d, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
-            (J.conv && hipMemcpyAsync(pin_conv + p0, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess) ||
+            hipMemcpyAsync(to_rgb, d_out + p0 * d, pn * d, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess ||
+            (J.conv && hipMemcpyAsync(to_conv, d_conv + p0, pn, hipMemcpyDeviceToHost, L.copy_st) != hipSuccess) ||
             hipEventRecord(L.band_events[2 * b + 1], L.copy_st) != hipSuccess) { copy_err = 1; return false; }
         return true;
     };
@@ -494,6 +558,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         TraceRange tf("srcnn fan-out band %u", b);
         if (wait_event(L.band_events[2 * b + 1]) != hipSuccess) { copy_err = 1; return; }
         if (b + 1 == nb) us_landed = since();
+        if (out_pinned) return;                                 // the band landed in the caller's buffer itself
         const size_t p0 = (size_t)(cuts[b] - R0) * dw, pn = (size_t)(cuts[b + 1] - cuts[b]) * dw;
         const size_t g0 = (size_t)cuts[b] * dw;
         parallel_memcpy(J.out + g0 * d, pin_rgb + p0 * d, pn * d);
@@ -524,9 +589,14 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         TraceRange tb("srcnn band %u [%u,%u)", b, cuts[b], cuts[b + 1]);
         unsigned upto = hi;
         launch_rc = band_source_end(cuts[b], cuts[b + 1], upto);
+        // the plane shell splits the staged rows with a kernel on the compute stream: chain before it; the fused shell's first
+        // launch is the band's resampler: stage first (the copy runs beside the previous job's kernels), then chain
+        if (!launch_rc && !fused_shell) launch_rc = chain_in();
         if (!launch_rc) launch_rc = stage_rows(b + 1 == nb ? hi : upto);
+        if (!launch_rc) launch_rc = chain_in();
         if (!launch_rc) launch_rc = run_band(cuts[b], cuts[b + 1]);
         if (!launch_rc && hipEventRecord(L.band_events[2 * b], s) != hipSuccess) launch_rc = fail(SRCNN_E_HIP, "band %u event record failed", b);
+        if (!launch_rc && b + 1 == nb) chain_out();
         if (launch_rc) { enqueued.cancel(); break; }
         if (b == 0) us_first_queued = since();
         if (threaded) enqueued.publish(b + 1);
@@ -649,8 +719,20 @@ int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigne
     return srcnn_y_upscale2x_f32_stream(in, w, h, nframes, out, 0);
 }
 
+namespace {
+int process_u8_impl(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
+                    unsigned char* out, unsigned char* conv_opt, AsyncLink* after, AsyncLink* mine);
+}
+
 int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
                      unsigned char* out, unsigned char* conv_opt)
+{
+    return process_u8_impl(rgb, w, h, d, multiply, filter, out, conv_opt, nullptr, nullptr);
+}
+
+namespace {
+int process_u8_impl(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
+                    unsigned char* out, unsigned char* conv_opt, AsyncLink* after, AsyncLink* mine)
 {
     if (!rgb || !out || w == 0 || h == 0 || d == 0) return fail(SRCNN_E_ARG, "NULL pointer or zero dimension");
     if (d != 3 && d != 4) return fail(SRCNN_E_UNSUPPORTED, "depth %u: the reference reads uninitialised planes for d<3 (src/libsrcnn.cpp:235-236)", d);
@@ -675,7 +757,11 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
     const size_t out_bytes = (size_t)dw * dh * d;
     unsigned shares = 1;
     if (out_bytes >= (8u << 20)) shares = std::max(1u, std::min<unsigned>((unsigned)context_count(), dh / 256u));
-    if (shares <= 1) return process_share(*cur, J, 0, dh, false);
+    if (shares <= 1) {
+        J.after = after; J.mine = mine;            // the chain orders kernels on ONE device; a dealt-out image runs unchained
+        return process_share(*cur, J, 0, dh, false);
+    }
+    if (mine) mine->settle(false);                 // nothing to wait for: the next job starts beside this one
 
     std::vector<int> rcs(shares, SRCNN_OK);
     std::vector<std::string> errs(shares);
@@ -698,6 +784,7 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
         if (rcs[k]) { set_last_error(errs[k].c_str()); return rcs[k]; }
     return SRCNN_OK;
 }
+}  // namespace
 
 // ---- the same call, asynchronous: begin() returns at once, wait() joins ----
 // A caller that upscales a SEQUENCE of images keeps the device busy across calls this way: while image i's last band is
@@ -706,12 +793,18 @@ int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned 
 // bands are already queued on another lane.  Each job runs srcnn_process_u8 on a thread of its own with the caller's
 // current context; up to SRCNN_MAX_LANES jobs per context make progress at once, further ones queue for a lane like
 // concurrent synchronous callers do.  The buffers must stay valid and untouched until wait() returns.
+// The KERNELS of consecutive jobs of a context are chained (AsyncLink): job k+1's first kernel waits on the device for job k's
+// last, while its stage-in copy and job k's copy-out run beside them -- two jobs sharing the device measured SLOWER than
+// blocking calls (13.2 vs 10.7 ms per 4K image, profiles/r04_process_clock.txt).
 namespace {
 struct AsyncJob {
     std::thread th;
     int rc = SRCNN_OK;
     std::string err;
+    std::shared_ptr<AsyncLink> after, mine;
 };
+std::mutex g_async_mu;
+std::map<int, std::shared_ptr<AsyncLink>> g_async_tail;        // per context: the link of the job begun last
 }  // namespace
 
 int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
@@ -724,15 +817,21 @@ int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, uns
     const int ctx_index = cur->index;
     AsyncJob* a = new (std::nothrow) AsyncJob;
     if (!a) return fail(SRCNN_E_OUTALLOC, "out of memory");
-    const bool ok = try_thread(a->th, [=] {
-        (void)srcnn_set_context(ctx_index);                   // the worker inherits the caller's current context
-        a->rc = srcnn_process_u8(rgb, w, h, d, multiply, filter, out, conv_opt);
-        if (a->rc) a->err = srcnn_last_error();
-    });
-    if (!ok) {                                                // no thread to be had: degrade to the synchronous call
-        a->rc = srcnn_process_u8(rgb, w, h, d, multiply, filter, out, conv_opt);
-        if (a->rc) a->err = srcnn_last_error();
+    static const bool chain = [] { const char* e = getenv("SRCNN_ASYNC_CHAIN"); return !(e && e[0] == '0'); }();      // A/B runs
+    if (chain) {
+        a->mine = std::make_shared<AsyncLink>();
+        std::lock_guard<std::mutex> lk(g_async_mu);
+        auto& tail = g_async_tail[ctx_index];
+        a->after = tail;
+        tail = a->mine;
     }
+    auto work = [=] {
+        (void)srcnn_set_context(ctx_index);                   // the worker inherits the caller's current context
+        a->rc = process_u8_impl(rgb, w, h, d, multiply, filter, out, conv_opt, a->after.get(), a->mine.get());
+        if (a->rc) a->err = srcnn_last_error();
+        if (a->mine) a->mine->settle(false);                  // a job that never recorded its link (error, dealt-out image) releases its successor
+    };
+    if (!try_thread(a->th, work)) work();                     // no thread to be had: degrade to the synchronous call
     *job = a;
     return SRCNN_OK;
 }

@@ -87,6 +87,37 @@ def test_async_process_jobs_keep_several_images_in_flight(srcnn, oracle_lib, gol
     assert L.srcnn_process_u8_begin(big.ctypes.data, 4, 4, 3, 2.0, 2, out.ctypes.data, None, None) == -1
 
 
+def test_page_locked_caller_buffers_skip_the_staging_and_give_the_same_bytes(srcnn, oracle_lib):
+    """A banded image whose source and result buffers are page-locked (srcnn_host_alloc_pinned): H2D straight from the caller's
+    image, every band's D2H straight into the caller's result -- the oracle's bytes, with and without conv-Y, blocking and as
+    chained asynchronous jobs; mixed (pinned in, pageable out and the reverse) too."""
+    S = srcnn
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (1080, 1920, 4), dtype=np.uint8)
+    want_rgb, want_conv = oracle_lib.process(img, 2.0)
+    pin_in = S.PinnedArray(img.shape); pin_in.array[...] = img
+    pin_out = S.PinnedArray(want_rgb.shape); pin_conv = S.PinnedArray(want_conv.shape)
+    L = S.lib()
+    try:
+        for src, out, conv in ((pin_in.array, pin_out.array, pin_conv.array), (pin_in.array, pin_out.array, None),
+                               (img, pin_out.array, pin_conv.array), (pin_in.array, np.empty_like(want_rgb), np.empty_like(want_conv)),
+                               (pin_in.array, pin_out.array, np.empty_like(want_conv))):
+            out[...] = 0
+            if conv is not None:
+                conv[...] = 0
+            S.check(L.srcnn_process_u8(src.ctypes.data, 1920, 1080, 4, 2.0, 2, out.ctypes.data, conv.ctypes.data if conv is not None else None))
+            assert np.array_equal(out, want_rgb)
+            assert conv is None or np.array_equal(conv, want_conv)
+        pin_out2 = S.PinnedArray(want_rgb.shape)
+        jobs = [S.ProcessJob(pin_in.array, want_conv=False, out=o) for o in (pin_out.array, pin_out2.array)]
+        for j in jobs:
+            got, _ = j.result()
+            assert np.array_equal(got, want_rgb)
+        pin_out2.free()
+    finally:
+        pin_in.free(); pin_out.free(); pin_conv.free()
+
+
 def test_profile_read_per_context(srcnn):
     S = srcnn
     y = synth.plane(64, 96, 3, "noise")

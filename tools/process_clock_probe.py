@@ -47,50 +47,52 @@ def summarize(name, recs, rows_of=None, wall_ms=None):
     return mhz, us
 
 
-print("# device:", S.device_name())
+ASYNC_ONLY = "--async-only" in sys.argv
+print("# device:", S.device_name(), "| SRCNN_ASYNC_CHAIN =", os.environ.get("SRCNN_ASYNC_CHAIN", "(default: chained)"))
 y = synth.plane(H, W, synth.SEED0, "smooth")
 d_in = S.DeviceBuffer.from_numpy(y)
 d_out = S.DeviceBuffer(4 * W * H * 4)
 
-# ---- (a) resident frames back to back ----
-for _ in range(4):
-    S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, W, H, d_out.ptr, None))
-S.sync()
-S.clock_probe(True)
-N = 24
-for _ in range(N):
-    S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, W, H, d_out.ptr, None))
-S.sync()
-ra = S.clock_read()
-S.clock_probe(False)
-mhz_a, us_a = summarize("(a) resident 4K frames, back to back", ra, N)
-cyc_round_a = np.median(mhz_a * us_a) / rounds(DH)
-print("    cycles per round of the grid: %.0f   (frame = %.2f rounds)" % (cyc_round_a, rounds(DH)))
+if not ASYNC_ONLY:
+    # ---- (a) resident frames back to back ----
+    for _ in range(4):
+        S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, W, H, d_out.ptr, None))
+    S.sync()
+    S.clock_probe(True)
+    N = 24
+    for _ in range(N):
+        S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, W, H, d_out.ptr, None))
+    S.sync()
+    ra = S.clock_read()
+    S.clock_probe(False)
+    mhz_a, us_a = summarize("(a) resident 4K frames, back to back", ra, N)
+    cyc_round_a = np.median(mhz_a * us_a) / rounds(DH)
+    print("    cycles per round of the grid: %.0f   (frame = %.2f rounds)" % (cyc_round_a, rounds(DH)))
 
-# ---- (b) the same frame as ProcessSRCNN's bands, back to back on one stream ----
-cuts = (C.c_uint * 16)()
-nb = L.srcnn_debug_band_plan(0, DH, DW, 0, cuts, 16)
-cuts = [cuts[i] for i in range(nb)]
-print("# band plan of a 7680x4320 output:", cuts)
-for _ in range(2):
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, W, H, a, b - a, d_out.ptr + a * DW * 4, None))
-S.sync()
-S.clock_probe(True)
-for _ in range(N):
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, W, H, a, b - a, d_out.ptr + a * DW * 4, None))
-S.sync()
-rb = S.clock_read()
-S.clock_probe(False)
-summarize("(b) the frame as %d bands, back to back" % (nb - 1), rb, N)
-per_band = len(cuts) - 1
-for k in range(per_band):
-    sel = rb[k::per_band]
-    m = np.array([r[0] for r in sel]); u = np.array([r[1] for r in sel])
-    rows = cuts[k + 1] - cuts[k] + (2 if k else 0) + (2 if k + 1 < per_band else 0)
-    print("    band %d rows %4d: MHz median %6.0f  us median %8.1f  cycles/round %.0f" % (k, cuts[k + 1] - cuts[k], np.median(m), np.median(u),
-                                                                                       np.median(m * u) / rounds(rows)))
+    # ---- (b) the same frame as ProcessSRCNN's bands, back to back on one stream ----
+    cuts = (C.c_uint * 16)()
+    nb = L.srcnn_debug_band_plan(0, DH, DW, 0, cuts, 16)
+    cuts = [cuts[i] for i in range(nb)]
+    print("# band plan of a 7680x4320 output:", cuts)
+    for _ in range(2):
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, W, H, a, b - a, d_out.ptr + a * DW * 4, None))
+    S.sync()
+    S.clock_probe(True)
+    for _ in range(N):
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            S.check(L.srcnn_y_upscale2x_f32_band_dev(d_in.ptr, W, H, a, b - a, d_out.ptr + a * DW * 4, None))
+    S.sync()
+    rb = S.clock_read()
+    S.clock_probe(False)
+    summarize("(b) the frame as %d bands, back to back" % (nb - 1), rb, N)
+    per_band = len(cuts) - 1
+    for k in range(per_band):
+        sel = rb[k::per_band]
+        m = np.array([r[0] for r in sel]); u = np.array([r[1] for r in sel])
+        rows = cuts[k + 1] - cuts[k] + (2 if k else 0) + (2 if k + 1 < per_band else 0)
+        print("    band %d rows %4d: MHz median %6.0f  us median %8.1f  cycles/round %.0f" % (k, cuts[k + 1] - cuts[k], np.median(m), np.median(u),
+                                                                                           np.median(m * u) / rounds(rows)))
 
 # ---- (c)/(d)/(e) ProcessSRCNN ----
 img = bench.synth_rgb(H, W, 0x5C0DE000 + 2160)
@@ -132,15 +134,53 @@ def run_calls(name, call, reps=12):
     return wall
 
 
-run_calls("(c) ProcessSRCNN 4K RGB, fresh result each call", call_dropin)
+if not ASYNC_ONLY:
+    run_calls("(c) ProcessSRCNN 4K RGB, fresh result each call", call_dropin)
 run_calls("(d) srcnn_process_u8 into a reused buffer", call_reused)
+
+# (f) page-locked caller buffers: no staging memcpy, no fan-out
+pin_img = S.PinnedArray(img.shape); pin_img.array[...] = img
+pin_a = S.PinnedArray(out.shape); pin_b = S.PinnedArray(out.shape)
+
+
+def call_pinned():
+    S.check(L.srcnn_process_u8(pin_img.array.ctypes.data, W, H, 3, 2.0, 2, pin_a.array.ctypes.data, None))
+
+
+run_calls("(f) srcnn_process_u8, page-locked source and result", call_pinned)
+assert np.array_equal(pin_a.array, out)
+
+
+def run_async(name, src, bufs, reps=24, depth=2):
+    for _ in range(2):
+        call_reused()
+    S.clock_probe(True)
+    t0 = time.perf_counter()
+    jobs = []
+    for i in range(reps):
+        j = C.c_void_p()
+        S.check(L.srcnn_process_u8_begin(src.ctypes.data, W, H, 3, 2.0, 2, bufs[i % len(bufs)].ctypes.data, None, C.byref(j)))
+        jobs.append(j)
+        if len(jobs) == depth:
+            S.check(L.srcnn_process_u8_wait(jobs.pop(0)))
+    while jobs:
+        S.check(L.srcnn_process_u8_wait(jobs.pop(0)))
+    wall = (time.perf_counter() - t0) * 1e3 / reps
+    recs = S.clock_read()
+    S.clock_probe(False)
+    summarize(name, recs, reps, wall)
+    print("    images per second: %.1f  = %.2f GPix/s through host u8 buffers" % (1e3 / wall, DW * DH / wall / 1e6))
+
+
+run_async("(g) two asynchronous jobs in flight, page-locked buffers", pin_img.array, [pin_a.array, pin_b.array])
+assert np.array_equal(pin_a.array, out) and np.array_equal(pin_b.array, out)
 
 # (e) two jobs in flight
 bufs = [out, out2]
 for _ in range(2):
     call_reused()
 S.clock_probe(True)
-reps = 12
+reps = 24
 t0 = time.perf_counter()
 jobs = []
 for i in range(reps):
