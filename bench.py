@@ -184,6 +184,46 @@ def process_srcnn_wall(S):
         "best_ms": round(min(ts) * 1e3, 2), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 2),
         "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
         "note": "srcnn_process_u8: host u8 RGB in -> caller-owned, reused host u8 RGB out, calls back to back"}
+    # Round 4: a SEQUENCE of images the way a caller that owns its buffers should run it -- page-locked source and result
+    # (srcnn_host_alloc_pinned: no staging memcpy, no fan-out) and two asynchronous jobs in flight whose kernels are chained
+    # on the device (srcnn_process_u8_begin / _wait): milliseconds per image over 16 images.
+    pin_img = S.PinnedArray(img.shape)
+    pin_img.array[...] = img
+    pins = [S.PinnedArray(res.shape), S.PinnedArray(res.shape)]
+    try:
+        ts = []
+        for it in range(7):
+            t0 = time.perf_counter()
+            rc = L.srcnn_process_u8(pin_img.array.ctypes.data, w, h, 3, 2.0, 2, pins[0].array.ctypes.data, None)
+            dt = time.perf_counter() - t0
+            assert rc == 0, rc
+            if it:
+                ts.append(dt)
+        out["3840x2160_rgb_page_locked_buffers"] = {
+            "best_ms": round(min(ts) * 1e3, 2), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 2),
+            "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
+            "note": "srcnn_process_u8, source and result allocated with srcnn_host_alloc_pinned, blocking calls back to back"}
+        same = bool(np.array_equal(pins[0].array, res))
+        n_img, jobs = 16, []
+        t0 = time.perf_counter()
+        for i in range(n_img):
+            j = C.c_void_p()
+            rc = L.srcnn_process_u8_begin(pin_img.array.ctypes.data, w, h, 3, 2.0, 2, pins[i & 1].array.ctypes.data, None, C.byref(j))
+            assert rc == 0, rc
+            jobs.append(j)
+            if len(jobs) == 2:
+                assert L.srcnn_process_u8_wait(jobs.pop(0)) == 0
+        while jobs:
+            assert L.srcnn_process_u8_wait(jobs.pop(0)) == 0
+        per = (time.perf_counter() - t0) / n_img
+        out["3840x2160_rgb_async_sequence"] = {
+            "ms_per_image": round(per * 1e3, 2), "MPix/s": round(4 * h * w / 1e6 / per, 1), "images": n_img,
+            "results_equal_blocking_call": bool(same and np.array_equal(pins[1].array, res) and np.array_equal(pins[0].array, res)),
+            "note": "srcnn_process_u8_begin/_wait, two jobs in flight, kernels chained on the device, page-locked buffers"}
+    finally:
+        pin_img.free()
+        for p in pins:
+            p.free()
     out["note"] = "host u8 RGB in -> host u8 RGB out through the drop-in symbol; includes H2D, colour split, chroma " \
                   "resample, Y path, merge, D2H and the new[] of the result"
     return out
