@@ -485,7 +485,14 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         AsyncLink& a = *J.after;
         std::unique_lock<std::mutex> lk(a.m);
         a.cv.wait(lk, [&] { return a.done; });
-        if (a.valid && a.ev) HIP_TRY(hipStreamWaitEvent(s, a.ev, 0));
+        if (a.valid && a.ev) {
+            // resolved on the HOST by default (this thread polls the predecessor's last-kernel event, then queues): a device-side
+            // hipStreamWaitEvent across streams is resolved by a thread of the runtime on this ROCm and measured slower
+            // (SRCNN_ASYNC_CHAIN=2 selects it for A/B runs)
+            static const bool device_side = [] { const char* e = getenv("SRCNN_ASYNC_CHAIN"); return e && e[0] == '2'; }();
+            if (device_side) HIP_TRY(hipStreamWaitEvent(s, a.ev, 0));
+            else if (wait_event(a.ev) != hipSuccess) return fail(SRCNN_E_HIP, "waiting for the previous asynchronous job's kernels");
+        }
         return SRCNN_OK;
     };
     auto chain_out = [&]() {          // right after this job's last launch on the compute stream

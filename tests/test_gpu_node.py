@@ -81,9 +81,14 @@ def test_env_srcnn_devices_self_init():
                                  {"SRCNN_MAX_WORKSPACE_MB": "48"}, {"SRCNN_RS_DMA": "0", "SRCNN_NUMA": "0"},
                                  # host-side switches (independent of one another, so they share runs)
                                  {"SRCNN_THP": "0", "SRCNN_PREFAULT_THREADS": "3", "SRCNN_SPIN_WAIT": "1", "SRCNN_DEVICE_WAIT_IN": "1"},
-                                 {"SRCNN_PREFAULT": "0", "SRCNN_BANDS": "0.03,0.07,0.2,0.3,0.3,0.05,0.02", "SRCNN_CONV12_SPREAD": "0", "SRCNN_CONV3_OFF64": "1"}],
+                                 {"SRCNN_PREFAULT": "0", "SRCNN_BANDS": "0.03,0.07,0.2,0.3,0.3,0.05,0.02", "SRCNN_CONV12_SPREAD": "0", "SRCNN_CONV3_OFF64": "1"},
+                                 # the two resampler switches ALONE (they used to leave the fused shell selected, whose RGB
+                                 # source only k_rs2d can read: every up-scaling call failed); the second run also deals the layer-1+2
+                                 # tiles with the static stride instead of the tile queue
+                                 {"SRCNN_RESAMPLE_2PASS": "1"}, {"SRCNN_RESAMPLE_OLD2D": "1", "SRCNN_CONV12_QUEUE": "0"}],
                          ids=["default", "unfused-shell", "round2-resampler", "two-pass", "tpb1", "small-budget", "no-dma-resampler-no-numa",
-                              "no-thp-3-prefaulters-runtime-waits-device-stage-in", "no-prefault-eight-bands-no-quarter-spread-conv3-64bit-offsets"])
+                              "no-thp-3-prefaulters-runtime-waits-device-stage-in", "no-prefault-eight-bands-no-quarter-spread-conv3-64bit-offsets",
+                              "two-pass-alone", "round2-resampler-alone-static-stride"])
 def test_processsrcnn_kernel_selections_all_bit_exact(env):
     """The fused colour shell / k_rs2d (default) and every fallback they replace produce the oracle's bytes; so does a
     workspace budget small enough to force many bands inside srcnn_process_u8."""
