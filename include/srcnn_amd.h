@@ -235,7 +235,9 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
 /* One doSRCNN pass on an interleaved 8-bit RGB(A) image, fully on the device
  * (src/libsrcnn.cpp:628-923): colour split :233-272, per-plane resample :665-726, Y convolutions,
  * merge + clamp + truncate :274-308, optional truncated conv-Y :889-905.
- * out: (w*m)*(h*m)*d bytes, conv_opt: (w*m)*(h*m) bytes or NULL; both caller-allocated host memory. */
+ * out: (w*m)*(h*m)*d bytes, conv_opt: (w*m)*(h*m) bytes or NULL; both caller-allocated host memory.
+ * Buffers that come from srcnn_host_alloc_pinned are copied from / into directly (no staging memcpy, no fan-out): what a
+ * caller with a sequence of images should use (10.0 instead of 10.3-11.7 ms per 3840x2160 RGB image). */
 int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply,
                      int filter, unsigned char* out, unsigned char* conv_opt);
 

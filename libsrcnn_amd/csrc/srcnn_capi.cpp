@@ -384,6 +384,25 @@ Workspace* workspace_for(Ctx& cx, hipStream_t s)
 // ProcessSRCNN shares one output staging), and placed on the NUMA node next to the device when the platform tells us
 // which one that is (hipHostMallocNumaUser: the allocation follows the calling thread's memory policy, which is set to
 // "prefer that node" around the call).  SRCNN_NUMA=0 disables the placement.
+// The blocks handed out by srcnn_host_alloc_pinned: how srcnn_process_u8 recognises caller buffers it can copy from / into
+// directly (asking the runtime about a pageable pointer works too, but logs an error line per question under AMD_LOG_LEVEL >= 1).
+std::mutex g_pinned_mu;
+std::map<uintptr_t, size_t>& pinned_blocks()
+{
+    static auto* m = new std::map<uintptr_t, size_t>;
+    return *m;
+}
+bool pinned_by_library(const void* p, size_t n)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    auto& m = pinned_blocks();
+    auto it = m.upper_bound(a);
+    if (it == m.begin()) return false;
+    --it;
+    return a >= it->first && a + n <= it->first + it->second;
+}
+
 void* pinned_alloc(Ctx& cx, size_t bytes)
 {
     void* p = nullptr;
@@ -1028,6 +1047,7 @@ int srcnn_get_context(void) { return t_ctx; }
 void srcnn_shutdown(void)
 {
     srcnn_comm_destroy();
+    async_chain_reset();
     std::vector<std::unique_ptr<Ctx>> dying;
     {
         std::lock_guard<std::mutex> lk(G.mu);
@@ -1114,9 +1134,16 @@ void* srcnn_host_alloc_pinned(size_t bytes)
 {
     Ctx* cx = cur_ctx();
     if (!cx) return nullptr;
-    return pinned_alloc(*cx, bytes);
+    void* p = pinned_alloc(*cx, bytes);
+    if (p) { std::lock_guard<std::mutex> lk(g_pinned_mu); pinned_blocks()[reinterpret_cast<uintptr_t>(p)] = bytes ? bytes : 1; }
+    return p;
 }
-void srcnn_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+void srcnn_host_free_pinned(void* p)
+{
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(g_pinned_mu); pinned_blocks().erase(reinterpret_cast<uintptr_t>(p)); }
+    (void)hipHostFree(p);
+}
 
 int srcnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 {

@@ -75,10 +75,14 @@ void abort_comm(ncclComm_t comm)
 class Watchdog {
 public:
     // arm() .. disarm() brackets one blocking call; returns through `fired` whether the deadline hit
+    // One armed region at a time: a second thread's RCCL call waits here until the first has returned (or its deadline has
+    // aborted the communicator) -- the regions are the host-side queueing calls, microseconds long unless a peer is missing.
     void arm(ncclComm_t comm)
     {
         const int ms = g_timeout_ms.load();
         if (ms <= 0) return;
+        region_.lock();
+        owner_armed_ = true;
         std::lock_guard<std::mutex> lk(m_);
         if (!started_) { th_ = std::thread([this] { run(); }); th_.detach(); started_ = true; }
         comm_ = comm; fired_ = false; armed_ = true;
@@ -87,10 +91,17 @@ public:
     }
     bool disarm()
     {
-        std::lock_guard<std::mutex> lk(m_);
-        armed_ = false;
-        cv_.notify_all();
-        return fired_;
+        bool fired;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (!owner_armed_) return false;         // arm() was a no-op (no deadline configured)
+            armed_ = false;
+            fired = fired_;
+            owner_armed_ = false;
+            cv_.notify_all();
+        }
+        region_.unlock();
+        return fired;
     }
 private:
     void run()
@@ -108,10 +119,10 @@ private:
             }
         }
     }
-    std::mutex m_;
+    std::mutex m_, region_;
     std::condition_variable cv_;
     std::thread th_;
-    bool started_ = false, armed_ = false, fired_ = false;
+    bool started_ = false, armed_ = false, fired_ = false, owner_armed_ = false;
     ncclComm_t comm_ = nullptr;
     std::chrono::steady_clock::time_point deadline_;
 };
@@ -290,9 +301,10 @@ int srcnn_comm_destroy(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_comm) return SRCNN_OK;
     (void)hipSetDevice(g_device);
-    if (g_poisoned.load()) {
-        // aborted after a missed deadline: its kernels have been told to quit; a destroy would wait for peers that are gone
-        if (R.CommAbort) (void)R.CommAbort(g_comm);
+    if (g_poisoned.load() && R.CommAbort) {
+        // aborted after a missed deadline: ncclCommAbort has already ended its kernels and freed the communicator
+    } else if (g_poisoned.load()) {
+        // (a librccl without ncclCommAbort: nothing was aborted; do not wait for peers that are gone -- the object is leaked)
     } else {
         hipDeviceSynchronize();
         R.CommDestroy(g_comm);

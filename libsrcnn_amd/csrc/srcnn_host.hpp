@@ -252,6 +252,7 @@ int get_table(Call& c, int filter, unsigned dst_len, unsigned src_len, TableRef&
 Workspace* workspace_for(Ctx& cx, hipStream_t s);
 void* pinned_alloc(Ctx& cx, size_t bytes);      // page-locked, visible to every device, on the context's NUMA node
 int grow_pinned(Ctx& cx, unsigned char*& p, size_t& have, size_t want);
+bool pinned_by_library(const void* p, size_t n);   // [p, p+n) lies inside a block from srcnn_host_alloc_pinned
 
 // ---- the path (srcnn_capi.cpp) ----
 int check_plane(const void* in, unsigned w, unsigned h, const void* out);
@@ -275,6 +276,7 @@ std::vector<unsigned> tiled_cuts(unsigned out_w, unsigned out_h, int rank, int n
 // memcpy split over a few host threads: the destination is usually a fresh new[] block whose pages fault in on first
 // touch, which a single thread does at only a few GB/s.
 void parallel_memcpy(void* dst, const void* src, size_t n);
+void async_chain_reset();     // srcnn_shutdown: forget the chain links of asynchronous ProcessSRCNN jobs (they own events)
 
 // Host waits.  On this runtime hipEventSynchronize / hipStreamSynchronize hold a core at 100 % for the whole wait, whatever the
 // event's flags -- hipEventBlockingSync included; only the process-wide hipDeviceScheduleBlockingSync changes that, and that

@@ -401,12 +401,12 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 
     const size_t out_bytes = share_px * d;
     const bool small = out_bytes < (8u << 20) && !one_of_many;
-    // Buffers the caller allocated page-locked (srcnn_host_alloc_pinned / hipHostMalloc) need no staging: the source rows go
+    // Buffers the caller allocated page-locked with srcnn_host_alloc_pinned need no staging: the source rows go
     // to the device straight from the caller's image and every band lands straight in the caller's result.  That removes the
     // 125 MB of staging memcpy and the 100 MB fan-out per 4K image that bound a SEQUENCE of calls on the host
     // (profiles/r04_process_clock.txt: 10.8 ms per image blocking, 11.5 with two jobs in flight, for 9 ms of device work).
-    const bool in_pinned = !small && is_pinned(J.rgb);
-    const bool out_pinned = !small && is_pinned(J.out) && (!J.conv || is_pinned(J.conv));
+    const bool in_pinned = !small && pinned_by_library(J.rgb, n * d);
+    const bool out_pinned = !small && pinned_by_library(J.out, (size_t)dw * dh * d) && (!J.conv || pinned_by_library(J.conv, (size_t)dw * dh));
     // ---- stage-in.  Small images: the share's source rows in one go, straight from the caller's (pageable) buffer.  Large
     //      images: band by band -- stage_rows(upto) brings source rows [staged, upto) through the page-locked staging to the
     //      device (and, on the plane path, splits them), so the first band's kernels start after a third of the copy and the
@@ -803,6 +803,8 @@ int process_u8_impl(const unsigned char* rgb, unsigned w, unsigned h, unsigned d
 // The KERNELS of consecutive jobs of a context are chained (AsyncLink): job k+1's first kernel waits on the device for job k's
 // last, while its stage-in copy and job k's copy-out run beside them -- two jobs sharing the device measured SLOWER than
 // blocking calls (13.2 vs 10.7 ms per 4K image, profiles/r04_process_clock.txt).
+}  // extern "C"
+
 namespace {
 struct AsyncJob {
     std::thread th;
@@ -811,8 +813,24 @@ struct AsyncJob {
     std::shared_ptr<AsyncLink> after, mine;
 };
 std::mutex g_async_mu;
-std::map<int, std::shared_ptr<AsyncLink>> g_async_tail;        // per context: the link of the job begun last
+// per context: the link of the job begun last.  On the heap and never destroyed by a static destructor (the HIP runtime may be
+// gone by then, and a link owns an event); srcnn_shutdown drops the links while the devices are still there.
+std::map<int, std::shared_ptr<AsyncLink>>& async_tails()
+{
+    static auto* m = new std::map<int, std::shared_ptr<AsyncLink>>;
+    return *m;
+}
 }  // namespace
+
+namespace srcnn {
+void async_chain_reset()
+{
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    async_tails().clear();
+}
+}  // namespace srcnn
+
+extern "C" {
 
 int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
                            unsigned char* out, unsigned char* conv_opt, void** job)
@@ -828,7 +846,7 @@ int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, uns
     if (chain) {
         a->mine = std::make_shared<AsyncLink>();
         std::lock_guard<std::mutex> lk(g_async_mu);
-        auto& tail = g_async_tail[ctx_index];
+        auto& tail = async_tails()[ctx_index];
         a->after = tail;
         tail = a->mine;
     }

@@ -118,6 +118,32 @@ def test_page_locked_caller_buffers_skip_the_staging_and_give_the_same_bytes(src
         pin_in.free(); pin_out.free(); pin_conv.free()
 
 
+def test_fresh_lanes_every_time(srcnn, oracle_lib):
+    """Everything a lane owns is created on first use (streams, scratch, the layer kernel's tile queue ...) and the first call of
+    a fresh lane once read an un-zeroed queue (found in round 4).  So: shut the library down and bring it up again eight
+    times, each time with three jobs in flight at once -- three lanes that have never run anything -- on a banded image and a
+    small one; every result is the oracle's."""
+    S = srcnn
+    rng = np.random.default_rng(11)
+    big = rng.integers(0, 256, (900, 1500, 3), dtype=np.uint8)
+    small = rng.integers(0, 256, (70, 90, 4), dtype=np.uint8)
+    want_big, want_small = oracle_lib.process(big, 2.0), oracle_lib.process(small, 2.0)
+    y = synth.plane(200, 300, 77, "noise")
+    want_y = oracle_lib.y_path(y)
+    try:
+        for k in range(8):
+            S.shutdown()
+            S.init(0)
+            jobs = [S.ProcessJob(big), S.ProcessJob(small), S.ProcessJob(big, want_conv=False)]
+            assert_bit_equal(S.y_upscale2x(y), want_y, "float path beside fresh lanes, cycle %d" % k)      # a fresh stream workspace too
+            r = [j.result() for j in jobs]
+            assert np.array_equal(r[0][0], want_big[0]) and np.array_equal(r[0][1], want_big[1]), k
+            assert np.array_equal(r[1][0], want_small[0]) and np.array_equal(r[1][1], want_small[1]), k
+            assert np.array_equal(r[2][0], want_big[0]), k
+    finally:
+        S.init(0)
+
+
 def test_profile_read_per_context(srcnn):
     S = srcnn
     y = synth.plane(64, 96, 3, "noise")
