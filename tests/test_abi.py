@@ -53,6 +53,33 @@ def test_reference_argument_checks_need_no_device(S):
     assert S.ProcessSRCNN(img, 4, 4, 3, -1.0)[0] == -2
 
 
+def test_round4_settings_need_no_device(S):
+    """The mode / relaxation mask and the comm deadline are plain settings (no device touched): values are validated, setters
+    return the previous value, the asynchronous ProcessSRCNN pair and the bounded comm wait fail cleanly without a device /
+    communicator, and the registry behind the page-locked fast path knows only blocks the library handed out."""
+    import ctypes as C
+    L = S.lib()
+    assert L.srcnn_get_mode() == S.MODE_STRICT
+    assert L.srcnn_set_relaxation(S.RELAX_L1 | S.RELAX_L3_X64) == S.RELAX_L3_X64           # default mask: exact layer-3 products
+    assert L.srcnn_set_mode(S.MODE_RELAXED) == S.MODE_STRICT and L.srcnn_get_mode() == S.MODE_RELAXED
+    assert L.srcnn_set_relaxation(0) == (S.RELAX_L1 | S.RELAX_L3_X64) and L.srcnn_get_mode() == S.MODE_RELAXED
+    assert L.srcnn_set_relaxation(16) < 0 and L.srcnn_set_relaxation(S.RELAX_L3_X64 | S.RELAX_L3_F32) < 0
+    assert L.srcnn_set_mode(7) < 0
+    assert L.srcnn_set_mode(S.MODE_STRICT) == S.MODE_RELAXED
+    assert L.srcnn_set_relaxation(S.RELAX_L3_X64) == 0
+    prev = L.srcnn_comm_set_timeout_ms(1234)
+    assert prev == int(__import__("os").environ.get("SRCNN_COMM_TIMEOUT_MS", 60000))
+    assert L.srcnn_comm_set_timeout_ms(prev) == 1234 and L.srcnn_comm_set_timeout_ms(-5) < 0
+    assert L.srcnn_comm_wait(None) == -204                                                 # no communicator
+    if S.device_count() == 0:
+        job = C.c_void_p()
+        buf = np.zeros(64, np.uint8)
+        assert L.srcnn_process_u8_begin(buf.ctypes.data, 2, 2, 3, 2.0, 2, buf.ctypes.data, None, C.byref(job)) == -200
+        assert not job.value
+        assert not L.srcnn_host_alloc_pinned(4096)
+        assert L.srcnn_debug_clock_probe(1) == -200
+
+
 def test_no_cpu_fallback(S):
     if S.device_count() > 0:
         pytest.skip("a GPU is present")
