@@ -245,7 +245,15 @@ struct AsyncLink {
     }
     void mark_leased() { { std::lock_guard<std::mutex> lk(m); leased = true; } cv.notify_all(); }
     void wait_leased() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return leased; }); }
-    ~AsyncLink() { if (ev) { (void)hipSetDevice(device); (void)hipEventDestroy(ev); } }
+    ~AsyncLink()
+    {
+        if (!ev) return;
+        int cur = -1;                              // (the last reference may go on an application thread: leave its device as it was)
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        (void)hipEventDestroy(ev);
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
 };
 
 struct ProcJob {            // one srcnn_process_u8 call; shared (read-only) by its per-context workers
@@ -483,8 +491,11 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if (chained_in || !J.after) return SRCNN_OK;
         chained_in = true;
         AsyncLink& a = *J.after;
-        std::unique_lock<std::mutex> lk(a.m);
-        a.cv.wait(lk, [&] { return a.done; });
+        {
+            std::unique_lock<std::mutex> lk(a.m);
+            a.cv.wait(lk, [&] { return a.done; });
+        }
+        // (settled links never change again: valid / ev are read without the lock, which the wait below must not hold)
         if (a.valid && a.ev) {
             // resolved on the HOST by default (this thread polls the predecessor's last-kernel event, then queues): a device-side
             // hipStreamWaitEvent across streams is resolved by a thread of the runtime on this ROCm and measured slower
