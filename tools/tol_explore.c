@@ -1,7 +1,7 @@
 /*
  * tol_explore.c -- CPU emulation of RELAXED evaluations of the three SRCNN layers, to see which of the reference's
  * roundings (src/libsrcnn.cpp:395-410 conv 9x9, :433-437 conv 1x1, :500-517 conv 5x5) can be given up inside a
- * |dY| <= 1e-4 budget.  DEVELOPMENT TOOL (uses the oracle's weight table; never part of the product).  Each relaxed form
+ * |dY| <= 1e-4 budget.  DEVELOPMENT TOOL (a CPU emulation with the product's weight table; never part of the product, never used as a checker).  Each relaxed form
  * below is the exact arithmetic of a candidate device instruction sequence:
  *   layer 1/2  "fma"  : acc = fmaf(w, x, acc)            (MFMA with C = acc: one rounding per tap instead of two)
  *              masks  : only the taps / channels whose weights are smallest take the fma form, the rest stay strict
@@ -25,7 +25,7 @@
 #define C1 64
 #define C2 32
 static const uint32_t k_weight_bits[8129] = {
-#include "../oracle/oracle_weights.inc"
+#include "../libsrcnn_amd/csrc/srcnn_weights.inc"
 };
 #define OFF_B1 0
 #define OFF_W1 (OFF_B1 + 64)
