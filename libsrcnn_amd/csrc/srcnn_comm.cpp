@@ -68,7 +68,8 @@ std::atomic<int> g_timeout_ms{[] { const char* e = getenv("SRCNN_COMM_TIMEOUT_MS
 
 void abort_comm(ncclComm_t comm)
 {
-    g_poisoned = true;
+    if (g_poisoned.exchange(true)) return;               // once: the abort destroys the communicator
+    (void)hipSetDevice(g_device);                          // (the watchdog's own thread has never bound a device)
     if (R.CommAbort && comm) (void)R.CommAbort(comm);
 }
 

@@ -195,6 +195,48 @@ def cmd_comm_tiled(_):
     return res
 
 
+def cmd_comm_deadline(_):
+    """A missed deadline, provoked at world = 1: half a second of kernels queued on a stream, a 40 ms deadline, srcnn_comm_wait
+    on that stream.  Expected: SRCNN_E_COMM, the communicator aborted, every later comm call refused at once -- and after
+    srcnn_comm_destroy + a fresh srcnn_comm_init everything works again."""
+    from libsrcnn_amd import multigpu
+    import time
+    S.init(0)
+    L = S.lib()
+    multigpu.init_comm_from_torch_dist(None, 0, 1)
+    res = {}
+    h, w = 1080, 1920
+    y = synth.plane(h, w, 5, "smooth")
+    d_in = S.DeviceBuffer.from_numpy(y); d_out = S.DeviceBuffer(4 * h * w * 4)
+    st = S.Stream()
+    S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, w, h, d_out.ptr, st.handle)); st.sync()      # warm
+    res["prev_timeout"] = L.srcnn_comm_set_timeout_ms(40)
+    for _ in range(200):                                                                     # ~0.5 s of device work
+        S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, w, h, d_out.ptr, st.handle))
+    t0 = time.perf_counter()
+    res["wait_rc"] = L.srcnn_comm_wait(st.handle)
+    res["wait_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    res["wait_error"] = L.srcnn_last_error().decode()
+    res["barrier_after_rc"] = L.srcnn_comm_barrier(None)
+    res["barrier_after_error"] = L.srcnn_last_error().decode()
+    counts = (C.c_size_t * 1)(16); offs = (C.c_size_t * 1)(0)
+    res["gather_after_rc"] = L.srcnn_comm_gatherv_at_f32(d_in.ptr, counts, offs, d_out.ptr, 0, None)
+    st.sync()                                                                                # the kernels themselves are fine
+    res["destroy_rc"] = L.srcnn_comm_destroy()
+    L.srcnn_comm_set_timeout_ms(60000)
+    multigpu.init_comm_from_torch_dist(None, 0, 1)
+    res["barrier_new_comm_rc"] = L.srcnn_comm_barrier(None)
+    t = multigpu.TiledFrameGPU(w, h, 0, 1, nsub=3)
+    t.step(d_in, st.handle)
+    res["wait_new_comm_rc"] = L.srcnn_comm_wait(st.handle)
+    got = t.result()
+    S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, w, h, d_out.ptr, None)); S.sync()
+    res["tiled_equal"] = bool(np.array_equal(got.view(np.uint32), d_out.to_numpy(np.float32, (2 * h, 2 * w)).view(np.uint32)))
+    L.srcnn_comm_destroy()
+    st.destroy()
+    return res
+
+
 def cmd_env_devices(_):
     """A process that never calls srcnn_init*: SRCNN_DEVICES decides (set by the test)."""
     y = synth.plane(20, 24, 5, "noise")
