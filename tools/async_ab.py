@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""A/B of the asynchronous ProcessSRCNN pair with page-locked buffers (3840x2160 RGB x2): blocking srcnn_process_u8 calls vs two
+and three jobs in flight; run once per SRCNN_ASYNC_CHAIN setting (1 = host-resolved chain, the default; 2 = device-side stream
+wait; 0 = unchained).  Results: profiles/r04_process_clock.txt.   SRCNN_ASYNC_CHAIN=1 python3 tools/async_ab.py"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
