@@ -158,6 +158,27 @@ def test_profile_read_per_context(srcnn):
     assert S.lib().srcnn_profile_read_context(7, 0, None, None) == -1
 
 
+def test_clock_probe_records_every_layer12_launch(srcnn):
+    """srcnn_debug_clock_probe / _read (the instrument behind profiles/r04_process_clock.txt): one record per layer-1+2 launch,
+    in launch order, with a plausible shader clock and a duration that grows with the work; off again = nothing recorded."""
+    S = srcnn
+    small, big = synth.plane(135, 240, 1, "smooth"), synth.plane(540, 960, 2, "smooth")
+    S.y_upscale2x(small)
+    S.clock_probe(True)
+    try:
+        S.y_upscale2x(small); S.y_upscale2x(big); S.y_upscale2x(small)
+        recs = S.clock_read(0)
+    finally:
+        S.clock_probe(False)
+    assert len(recs) == 3, recs
+    for mhz, us in recs:
+        assert 800 < mhz < 3200 and us > 1, recs
+    assert recs[1][1] > 2 * recs[0][1] and recs[1][1] > 2 * recs[2][1], recs
+    S.clock_probe(True); S.clock_probe(False)               # switching it on resets the record
+    S.y_upscale2x(small)
+    assert S.lib().srcnn_debug_clock_read(0, None, None, 0) == 0
+
+
 def _mempolicy():
     libc = C.CDLL(None, use_errno=True)
     mode = C.c_int(-1)
