@@ -236,9 +236,10 @@ def test_cli_srcnntest_butterfly(srcnn, golden, tmp_path):
     src = tmp_path / "butterfly.ppm"
     with open(src, "wb") as f:
         f.write(b"P6\n256 256\n255\n" + b["rgb_in"].tobytes())
-    r = subprocess.run([exe, "--scale=2.0", "--filter=2", str(src)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, "--scale=2.0", "--filter=2", "--sequence=5", str(src)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Test Ok" in r.stdout
+    assert "sequence of 5 images" in r.stdout and "results equal the ProcessSRCNN bytes" in r.stdout, r.stdout
 
     def body(path, header_lines):
         raw = open(path, "rb").read()

@@ -4,7 +4,12 @@
 // src/test.cpp:56-80, P7 RGB_ALPHA).
 //
 //   srcnntest [--scale=<ratio>] [--step] [--filter=<0..4>] [--waitakey] [--devices=all|<id,id,...>] [--repeat=N]
-//             source.ppm [output.ppm]
+//             [--sequence=N] source.ppm [output.ppm]
+//
+// --sequence=N (not in the reference, whose harness times one blocking call, src/test.cpp:653-672): after the ProcessSRCNN
+// call, push the image N more times through the way a caller with a SEQUENCE of images should use the library -- page-locked
+// source and result buffers (srcnn_host_alloc_pinned) and two asynchronous jobs in flight (srcnn_process_u8_begin / _wait) --
+// check that every result equals the ProcessSRCNN bytes, and print the time per image.
 //
 // --waitakey pauses before exit like the reference's (src/test.cpp:735-742, there so that a human can watch the process'
 // memory for leaks).  --devices selects the GPUs ONE ProcessSRCNN call may use (default: device 0; "all": every visible
@@ -100,6 +105,7 @@ int main(int argc, char** argv)
     bool step = false, waitakey = false;
     std::string devices;
     int repeat = 1;                          // --repeat=N: call ProcessSRCNN N times, report every wall time
+    int sequence = 0;                        // --sequence=N: N more images through the asynchronous page-locked path
     SRCNNFilterType filt = SRCNNF_Bicubic;
     std::string src, dst;
     for (int i = 1; i < argc; ++i) {
@@ -109,6 +115,7 @@ int main(int argc, char** argv)
         else if (a.rfind("--waitakey", 0) == 0) waitakey = true;
         else if (a.rfind("--devices=", 0) == 0) devices = a.substr(10);
         else if (a.rfind("--repeat=", 0) == 0) repeat = std::max(1, atoi(a.c_str() + 9));
+        else if (a.rfind("--sequence=", 0) == 0) sequence = std::max(0, atoi(a.c_str() + 11));
         else if (a.rfind("--filter=", 0) == 0) {
             const int v = atoi(a.c_str() + 9);
             filt = (v >= 0 && v <= 4) ? (SRCNNFilterType)v : SRCNNF_Bicubic;
@@ -117,7 +124,7 @@ int main(int argc, char** argv)
     }
     if (src.empty()) {
         printf("usage: %s [--scale=<ratio>] [--step] [--filter=<0 nearest|1 bilinear|2 bicubic|3 lanczos3|4 b-spline>] "
-               "[--waitakey] [--devices=all|<id,id,...>] [--repeat=N] source.(ppm|pgm|pam) [output]\n", argv[0]);
+               "[--waitakey] [--devices=all|<id,id,...>] [--repeat=N] [--sequence=N] source.(ppm|pgm|pam) [output]\n", argv[0]);
         return 0;
     }
     std::vector<unsigned char> img;
@@ -169,6 +176,36 @@ int main(int argc, char** argv)
         return -4;
     }
     int ret = 0;
+    if (sequence > 0 && !step) {
+        // the sequence path: one doSRCNN pass per image (no step scaling), buffers page-locked, two jobs in flight
+        const size_t in_n = (size_t)w * h * d, out_n = (size_t)ow * oh * d;
+        unsigned char* pin_in = static_cast<unsigned char*>(srcnn_host_alloc_pinned(in_n));
+        unsigned char* pin_out[2] = {static_cast<unsigned char*>(srcnn_host_alloc_pinned(out_n)),
+                                     static_cast<unsigned char*>(srcnn_host_alloc_pinned(out_n))};
+        if (!pin_in || !pin_out[0] || !pin_out[1]) { printf("- sequence: page-locked allocation failed (%s)\n", srcnn_last_error()); ret = -5; }
+        else {
+            memcpy(pin_in, img.data(), in_n);
+            void* job[2] = {nullptr, nullptr};
+            bool same = true;
+            int src_rc = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < sequence && !src_rc; ++i) {
+                src_rc = srcnn_process_u8_begin(pin_in, w, h, d, scale, (int)filt, pin_out[i & 1], nullptr, &job[i & 1]);
+                if (i && !src_rc) {
+                    src_rc = srcnn_process_u8_wait(job[(i - 1) & 1]); job[(i - 1) & 1] = nullptr;
+                    same = same && !src_rc && memcmp(pin_out[(i - 1) & 1], out, out_n) == 0;
+                }
+            }
+            for (int k = 0; k < 2; ++k)
+                if (job[k]) { const int r2 = srcnn_process_u8_wait(job[k]); if (!src_rc) src_rc = r2; same = same && !r2 && memcmp(pin_out[k], out, out_n) == 0; }
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (src_rc) { printf("- sequence failed, error code = %d (%s)\n", src_rc, srcnn_last_error()); ret = src_rc; }
+            else printf("- sequence of %d images (page-locked buffers, two asynchronous jobs in flight): %.2f ms per image, results %s the ProcessSRCNN bytes\n",
+                        sequence, ms / sequence, same ? "equal" : "DIFFER FROM");
+            if (!src_rc && !same) ret = -6;
+        }
+        srcnn_host_free_pinned(pin_in); srcnn_host_free_pinned(pin_out[0]); srcnn_host_free_pinned(pin_out[1]);
+    }
     if (!save_netpbm(dst, out, ow, oh, d)) { printf("- Failed to write %s\n", dst.c_str()); ret = -3; }
     else printf("- Saved %s (%ux%ux%u)\n", dst.c_str(), ow, oh, d);
     if (conv && convsz == ow * oh) {
