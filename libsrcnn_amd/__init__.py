@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrcnn_amd.so")
+# SRCNN_AMD_LIB: another build of the same library (A/B runs of two kernel versions on one box: tools/lib_ab.py)
+LIB_PATH = os.environ.get("SRCNN_AMD_LIB") or os.path.join(_HERE, "lib", "libsrcnn_amd.so")
 
 SRCNNF_Nearest, SRCNNF_Bilinear, SRCNNF_Bicubic, SRCNNF_Lanczos3, SRCNNF_Bspline = range(5)
 MODE_STRICT, MODE_FAST, MODE_FAST_F16, MODE_RELAXED = 0, 1, 2, 3
