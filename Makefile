@@ -1,5 +1,9 @@
 # Plain-make build of the product for C/C++ users (python -m libsrcnn_amd.build does the same).
-#   make            -> libsrcnn_amd/lib/libsrcnn_amd.so + libsrcnn_amd/bin/srcnntest
+#   make            -> libsrcnn_amd/lib/libsrcnn_amd.so + libsrcnn.so + libsrcnn.a + libsrcnn_amd/bin/srcnntest
+#                      libsrcnn.so / libsrcnn.a: the names the reference's Makefiles produce (Makefiles/Makefile.linux:13-14,
+#                      38-39) -- a program linked with -lsrcnn runs on this library without relinking
+#   make install    -> $(DESTDIR)$(PREFIX)/lib/{libsrcnn_amd.so,libsrcnn.so,libsrcnn.a}, include/{libsrcnn.h,srcnn_amd.h}
+#                      (the reference's install / uninstall: Makefiles/Makefile.linux:64-75)
 #   make oracle     -> the CPU checker (and oracle/_ref where the reference tree is present)
 #   make test       -> CPU test-suite;  make gpu-test on a gfx950 box
 #   make ubench     -> tools/ubench/bin/* (microbenchmarks; hipcc, gfx950)
@@ -13,9 +17,12 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fvisib
             -Wno-unused-result -Wno-unused-value -Wno-ignored-attributes -D__HIP_PLATFORM_AMD__
 SRCS    := srcnn_kernels.hip srcnn_fused_f16.hip srcnn_capi.cpp srcnn_pipeline.cpp srcnn_comm.cpp dropin.cpp
 OBJS    := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(basename $(SRCS))))
-HDRS    := $(CSRC)/srcnn_kernels.h $(CSRC)/srcnn_host.hpp $(CSRC)/resample_table.hpp $(CSRC)/srcnn_weights.inc include/srcnn_amd.h include/libsrcnn_dropin.h
+HDRS    := $(CSRC)/srcnn_kernels.h $(CSRC)/srcnn_host.hpp $(CSRC)/srcnn_settings.hpp $(CSRC)/resample_table.hpp $(CSRC)/srcnn_weights.inc include/srcnn_amd.h include/libsrcnn_dropin.h
 
-all: $(LIBDIR)/libsrcnn_amd.so $(BINDIR)/srcnntest
+PREFIX  ?= /usr/local
+ROCM    ?= /opt/rocm
+
+all: $(LIBDIR)/libsrcnn_amd.so $(LIBDIR)/libsrcnn.so $(LIBDIR)/libsrcnn.a $(BINDIR)/srcnntest
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(LIBDIR)
@@ -27,8 +34,20 @@ $(LIBDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
-$(LIBDIR)/libsrcnn_amd.so: $(OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OBJS) -o $@ -ldl
+# exports.map: only srcnn_* and the two reference symbols are exported (the kernels' launch stubs are not)
+$(LIBDIR)/libsrcnn_amd.so: $(OBJS) $(CSRC)/exports.map
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OBJS) -o $@ -ldl -Wl,-soname,libsrcnn_amd.so -Wl,--version-script=$(CSRC)/exports.map
+
+# libsrcnn.so: what a program linked against the reference's shared library asks the loader for (the reference links it
+# without a soname, so the request is the file name): a symbolic link to the product.  New links with -lsrcnn record the
+# product's soname (libsrcnn_amd.so), old binaries find the file they ask for.
+$(LIBDIR)/libsrcnn.so: $(LIBDIR)/libsrcnn_amd.so
+	ln -sf libsrcnn_amd.so $@
+
+# libsrcnn.a: the reference's DEFAULT artefact is the static library.  Consumers add the HIP runtime to their link line:
+#   g++ app.o -L<libdir> -lsrcnn -L$(ROCM)/lib -lamdhip64 -ldl -lpthread      (instead of the reference's -lsrcnn -fopenmp)
+$(LIBDIR)/libsrcnn.a: $(OBJS)
+	rm -f $@ && ar crs $@ $(OBJS)
 
 $(BINDIR)/srcnntest: tools/srcnntest.cpp $(LIBDIR)/libsrcnn_amd.so
 	@mkdir -p $(BINDIR)
@@ -72,7 +91,21 @@ asan: tests/host/_build/host_asan
 tsan: tests/host/_build/host_tsan
 	TSAN_OPTIONS=halt_on_error=1 $<
 
+install: all
+	install -d $(DESTDIR)$(PREFIX)/lib $(DESTDIR)$(PREFIX)/include
+	install -m 755 $(LIBDIR)/libsrcnn_amd.so $(DESTDIR)$(PREFIX)/lib/
+	ln -sf libsrcnn_amd.so $(DESTDIR)$(PREFIX)/lib/libsrcnn.so
+	install -m 644 $(LIBDIR)/libsrcnn.a $(DESTDIR)$(PREFIX)/lib/
+	install -m 644 include/libsrcnn_dropin.h $(DESTDIR)$(PREFIX)/include/libsrcnn.h
+	install -m 644 include/srcnn_amd.h $(DESTDIR)$(PREFIX)/include/srcnn_amd.h
+	@if [ -z "$(DESTDIR)" ] && [ "$$(id -u)" = 0 ]; then ldconfig; fi
+
+uninstall:
+	rm -f $(DESTDIR)$(PREFIX)/lib/libsrcnn_amd.so $(DESTDIR)$(PREFIX)/lib/libsrcnn.so $(DESTDIR)$(PREFIX)/lib/libsrcnn.a
+	rm -f $(DESTDIR)$(PREFIX)/include/libsrcnn.h $(DESTDIR)$(PREFIX)/include/srcnn_amd.h
+	@if [ -z "$(DESTDIR)" ] && [ "$$(id -u)" = 0 ]; then ldconfig; fi
+
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) oracle/_build oracle/_ref tests/host/_build tools/ubench/bin
 
-.PHONY: all oracle test gpu-test clean asan tsan ubench
+.PHONY: all oracle test gpu-test clean asan tsan ubench install uninstall

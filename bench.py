@@ -492,7 +492,13 @@ def side_workload(args):
     cpu0 = None
     if args.workload == "tiled8k":
         import hashlib
-        if world > ndev:
+        stand_in = os.environ.get("SRCNN_RCCL_LIB")
+        if stand_in:
+            # a rehearsal, not a measurement of xGMI: the ranks alias one device and move their bands through the test-suite's
+            # RCCL stand-in (tests/rccl_double) -- what it shows is that the N > 1 choreography runs and assembles the right frame
+            extra["rccl_library"] = stand_in
+            extra["ranks_alias_devices"] = world > ndev
+        if world > ndev and not stand_in:
             # the band gather is a real RCCL exchange, and RCCL refuses two ranks on one device
             if rank == 0:
                 print("bench.py: --workload tiled8k needs one GPU per rank (%d ranks, %d device(s) visible)" % (world, ndev), file=sys.stderr)

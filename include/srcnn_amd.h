@@ -35,9 +35,10 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define SRCNN_AMD_ABI_VERSION 4   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts
+#define SRCNN_AMD_ABI_VERSION 5   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts
                                    * 3: contexts (srcnn_init_devices ...), node-level calls, srcnn_trim, sub-band gather
-                                   * 4: SRCNN_MODE_RELAXED / srcnn_set_relaxation, srcnn_process_u8_begin/_wait, srcnn_comm_wait / srcnn_comm_set_timeout_ms */
+                                   * 4: SRCNN_MODE_RELAXED / srcnn_set_relaxation, srcnn_process_u8_begin/_wait, srcnn_comm_wait / srcnn_comm_set_timeout_ms
+                                   * 5: srcnn_debug_settings; gather tables verified across the ranks by default */
 
 /* error codes.  -1/-2/-11/-12/-100 are the reference's own (src/libsrcnn.cpp:951-966,883,910,636) */
 #define SRCNN_OK            0
@@ -271,6 +272,12 @@ int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, un
  * of ProcessSRCNN lanes created so far (at most 4 per context), both summed over the contexts. */
 int srcnn_debug_counts(int* tables, int* lanes);
 
+/* Every SRCNN_* environment switch of the library is read ONCE, when the library is loaded, into one table
+ * (libsrcnn_amd/csrc/srcnn_settings.hpp): this prints what the process runs with, one "NAME=value (default D)  -- effect" line
+ * per switch (markdown != 0: the table rows of DESIGN.md section 6).  The text is written to buf (NUL-terminated, truncated to
+ * cap; buf may be NULL); the return value is the length the whole text needs.  No device needed. */
+int srcnn_debug_settings(char* buf, size_t cap, int markdown);
+
 /* Diagnostic: the shader clock of every layer-1+2 launch.  While on, each launch records the shader-cycle and 100 MHz counters
  * over the lifetime of its first workgroup (cycles / ticks x 100 = MHz; ticks / 100 = microseconds).  probe(on) resets the
  * record and returns the previous setting; read() synchronises the device, returns the number of launches recorded on
@@ -325,8 +332,10 @@ int srcnn_comm_barrier(void* stream);
  * passes -- a rank died, or the ranks derived different gather tables -- the communicator is aborted (ncclCommAbort), the
  * call returns SRCNN_E_COMM, and every later srcnn_comm_* call fails at once until srcnn_comm_destroy + srcnn_comm_init.
  * Default 60000 ms, env SRCNN_COMM_TIMEOUT_MS; 0 = no deadline.  srcnn_comm_set_timeout_ms returns the previous value.
- * SRCNN_COMM_CHECK=1 additionally all-reduces a checksum of every new counts / offsets table before the first gather that
- * uses it, so that ranks which disagree return SRCNN_E_COMM together instead of pairing a send with the wrong receive. */
+ * srcnn_comm_destroy drains what is still queued under the same deadline and aborts instead of destroying on a miss.
+ * Before the first gather that uses a new counts / offsets table, a checksum of the table is all-reduced (16 bytes), so that
+ * ranks which disagree return SRCNN_E_COMM together instead of pairing a send with the wrong receive (SRCNN_COMM_CHECK=0
+ * skips it).  The tables the library derives itself depend on (width, height, ranks, pieces) only -- never on a switch. */
 int srcnn_comm_wait(void* stream);
 int srcnn_comm_set_timeout_ms(int ms);
 

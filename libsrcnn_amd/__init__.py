@@ -43,7 +43,7 @@ C_ABI_SYMBOLS = [
     "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_rank", "srcnn_comm_gather_f32",
     "srcnn_comm_gatherv_f32", "srcnn_comm_gatherv_at_f32", "srcnn_comm_tiled_y_upscale2x_f32_dev", "srcnn_band_rows", "srcnn_tiled_piece", "srcnn_debug_band_plan",
     "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_comm_wait", "srcnn_comm_set_timeout_ms", "srcnn_debug_counts", "srcnn_fused_diag",
-    "srcnn_debug_clock_probe", "srcnn_debug_clock_read",
+    "srcnn_debug_clock_probe", "srcnn_debug_clock_read", "srcnn_debug_settings",
 ]
 CXX_SYMBOLS = ["_Z20ConfigureFilterSRCNN15SRCNNFilterTypeb", "_Z12ProcessSRCNNPKhjjjfRPhRjPS1_Pj"]
 
@@ -115,6 +115,7 @@ def lib():
             "srcnn_debug_counts": (i, [C.POINTER(i), C.POINTER(i)]),
             "srcnn_fused_diag": (i, [vp, u, u, vp, vp, vp]),
             "srcnn_debug_clock_probe": (i, [i]), "srcnn_debug_clock_read": (i, [i, vp, vp, i]),
+            "srcnn_debug_settings": (i, [C.c_char_p, sz, i]),
             "srcnn_comm_barrier": (i, [vp]), "srcnn_comm_wait": (i, [vp]), "srcnn_comm_set_timeout_ms": (i, [i]),
         }
         for name, (res, args) in sig.items():
@@ -456,24 +457,56 @@ class PinnedArray:
 
 
 class ProcessJob:
-    """srcnn_process_u8_begin / _wait: the image is being produced; result() blocks and returns (rgb_out, conv_y|None)."""
+    """srcnn_process_u8_begin / _wait: the image is being produced; result() blocks and returns (rgb_out, conv_y|None).
+
+    The object owns the buffers a native worker thread reads and writes, so it must never be reclaimed while that thread is
+    still running: result(), leaving a `with` block and the finaliser all end in srcnn_process_u8_wait (the finaliser is what
+    covers a job dropped without result() -- e.g. the second constructor of `[ProcessJob(a), ProcessJob(b)]` raising)."""
 
     def __init__(self, rgb, multiply=2.0, filt=SRCNNF_Bicubic, want_conv=True, out=None, conv=None):
+        self.job = None
         self.rgb = np.ascontiguousarray(rgb, np.uint8)          # kept alive until the job is done
         h, w, d = self.rgb.shape
         m = np.float32(multiply)
         dw, dh = int(np.float32(w) * m), int(np.float32(h) * m)
         self.out = out if out is not None else np.empty((dh, dw, d), np.uint8)
         self.conv = (conv if conv is not None else np.empty((dh, dw), np.uint8)) if want_conv else None
-        self.job = C.c_void_p()
+        job = C.c_void_p()
         check(lib().srcnn_process_u8_begin(self.rgb.ctypes.data, w, h, d, float(m), filt, self.out.ctypes.data,
-                                           self.conv.ctypes.data if want_conv else None, C.byref(self.job)))
+                                           self.conv.ctypes.data if want_conv else None, C.byref(job)))
+        self.job = job
+
+    def _wait(self):
+        """Join the native job (idempotent); returns its code."""
+        if self.job is None:
+            return 0
+        job, self.job = self.job, None
+        return lib().srcnn_process_u8_wait(job)
 
     def result(self):
-        if self.job is not None:
-            job, self.job = self.job, None
-            check(lib().srcnn_process_u8_wait(job))
+        check(self._wait())
         return self.out, self.conv
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self._wait()
+        return False
+
+    def __del__(self):
+        try:
+            self._wait()          # the worker thread must be done with rgb / out / conv before they are freed
+        except Exception:
+            pass
+
+
+def debug_settings(markdown=False):
+    """The SRCNN_* switches this process runs with (srcnn_debug_settings): text, one line per switch.  No device needed."""
+    n = lib().srcnn_debug_settings(None, 0, 1 if markdown else 0)
+    buf = C.create_string_buffer(n + 1)
+    lib().srcnn_debug_settings(buf, n + 1, 1 if markdown else 0)
+    return buf.value.decode()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -13,8 +13,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrcnn_amd.so")
 
 SOURCES = ["srcnn_kernels.hip", "srcnn_fused_f16.hip", "srcnn_capi.cpp", "srcnn_pipeline.cpp", "srcnn_comm.cpp", "dropin.cpp"]
-DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "srcnn_host.hpp", "resample_table.hpp", "srcnn_weights.inc",
-                  "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h"]
+DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "srcnn_host.hpp", "srcnn_settings.hpp", "resample_table.hpp", "srcnn_weights.inc",
+                  "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h", "exports.map"]
 
 # -ffp-contract=off: strict kernels and the host table builder must round every multiply and add
 # separately (the reference binary contains no FMA).  FAST kernels call fmaf explicitly.
@@ -52,7 +52,7 @@ def source_digest():
 
 
 def stale():
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+    if not all(os.path.exists(p) for p in (LIB, STAMP, os.path.join(LIBDIR, "libsrcnn.so"), os.path.join(LIBDIR, "libsrcnn.a"))):
         return True
     try:
         return open(STAMP).read().strip() != source_digest()
@@ -74,7 +74,7 @@ def kernel_source_sha(name="k_conv12_mfma"):
     that kernel record it, and bench.py refuses to quote a counter taken from a different text.  Covered: the kernel's body
     (from its template header to the next banner comment) and, for the layer kernels, the constants its tile and LDS geometry
     are built from (M_* / m_* for k_conv12_mfma, C3_* for k_conv3), the LDS-DMA primitive rs_dma_dword they stage through, the
-    launchers that set grid, block and dynamic LDS (launch_v / launch_conv12_mfma / conv12_grid_info, launch_conv3) and the
+    launchers that set grid, block and dynamic LDS (launch_conv12_mfma / conv12_grid_info, launch_conv3) and the
     host function that picks the variant (run_conv12 in srcnn_capi.cpp)."""
     import hashlib
     import re
@@ -86,9 +86,8 @@ def kernel_source_sha(name="k_conv12_mfma"):
     parts = [src[m.start():end if end > 0 else len(src)]]
     extra = []
     if name == "k_conv12_mfma":
-        extra = [_region(src, r"constexpr int M_TW\b", r"\n// One tap-step"),
+        extra = [_region(src, r"constexpr int M_NW\b", r"\n// One tap-step"),
                  _region(src, r"__device__ __forceinline__ void rs_dma_dword\(", r"\n}\n"),
-                 _region(src, r"template <int NW, int PIPE, int WPS, bool LD>\nstatic void launch_v\(", r"\n}\n"),
                  _region(src, r"void conv12_grid_info\(", r"\n}\n"),
                  _region(src, r"void launch_conv12_mfma\(", r"\n}\n"),
                  _region(open(os.path.join(CSRC, "srcnn_capi.cpp")).read(), r"void run_conv12\(", r"\n}\n")]
@@ -117,10 +116,18 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    # exports.map: only srcnn_* and the two reference symbols are exported (not the kernels' launch stubs)
+    cmds = [[hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-ldl", "-Wl,-soname,libsrcnn_amd.so",
+                                                                             "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")],
+            # the names the reference's Makefiles produce (Makefiles/Makefile.linux:13-14,38-39): libsrcnn.so is a symbolic
+            # link to the product (old binaries ask the loader for that file name), libsrcnn.a the same objects as an archive
+            ["ln", "-sf", "libsrcnn_amd.so", os.path.join(LIBDIR, "libsrcnn.so")],
+            ["rm", "-f", os.path.join(LIBDIR, "libsrcnn.a")],
+            ["ar", "crs", os.path.join(LIBDIR, "libsrcnn.a")] + objs]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     build_cli(verbose)
     with open(STAMP, "w") as f:
         f.write(source_digest() + "\n")

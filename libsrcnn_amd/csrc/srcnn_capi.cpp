@@ -49,8 +49,7 @@ struct Roctx {
     int (*pop)() = nullptr;
     Roctx()
     {
-        const char* e = getenv("SRCNN_ROCTX");
-        if (!e || atoi(e) == 0) return;
+        if (!settings().roctx) return;
         void* h = nullptr;
         for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
             h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -78,23 +77,63 @@ TraceRange::TraceRange(const char* fmt, ...) : on_(roctx().push != nullptr)
 
 TraceRange::~TraceRange() { if (on_) (void)roctx().pop(); }
 
+// ---- settings: every SRCNN_* switch, read once (srcnn_settings.hpp) ----
+Settings Settings::from_env()
+{
+    Settings st;
+    auto get = [](const char* name) -> const char* { const char* v = getenv(name); return (v && *v) ? v : nullptr; };
+#define SRCNN_GET_B(m) st.m = atoi(v) != 0;
+#define SRCNN_GET_I(m) st.m = strtol(v, nullptr, 10);
+#define SRCNN_GET_S(m) st.m = v;
+#define X(kind, member, env, def, values, effect) if (const char* v = get(env)) { SRCNN_GET_##kind(member) }
+    SRCNN_SETTINGS(X)
+#undef X
+#undef SRCNN_GET_B
+#undef SRCNN_GET_I
+#undef SRCNN_GET_S
+    st.max_workspace_mb = std::max(st.max_workspace_mb, 1L);
+    st.max_lanes = std::min(64L, std::max(1L, st.max_lanes));
+    st.comm_timeout_ms = std::max(0L, st.comm_timeout_ms);
+    st.prefault_threads = std::max(1L, st.prefault_threads);
+    st.rs_tpb = std::min(16L, std::max(0L, st.rs_tpb));
+    st.async_chain = std::min(2L, std::max(0L, st.async_chain));
+    return st;
+}
+
+std::string Settings::describe(bool markdown) const
+{
+    std::string out;
+    char line[768];
+    auto val_b = [](bool b) { return std::string(b ? "1" : "0"); };
+    auto val_i = [](long i) { return std::to_string(i); };
+    auto val_s = [](const std::string& t) { return t.empty() ? std::string("(unset)") : t; };
+    const Settings defaults;
+#define SRCNN_VAL_B(m) val_b(m)
+#define SRCNN_VAL_I(m) val_i(m)
+#define SRCNN_VAL_S(m) val_s(m)
+#define X(kind, member, env, def, values, effect)                                                                                 \
+    if (markdown) snprintf(line, sizeof line, "| `%s` | **%s**; %s | %s |\n", env, SRCNN_VAL_##kind(defaults.member).c_str(), values, effect); \
+    else snprintf(line, sizeof line, "%s=%s (default %s)  -- %s\n", env, SRCNN_VAL_##kind(member).c_str(), SRCNN_VAL_##kind(defaults.member).c_str(), effect); \
+    out += line;
+    SRCNN_SETTINGS(X)
+#undef X
+#undef SRCNN_VAL_B
+#undef SRCNN_VAL_I
+#undef SRCNN_VAL_S
+    return out;
+}
+
+const Settings& settings()
+{
+    static const Settings* st = new Settings(Settings::from_env());      // (never destroyed, like Global)
+    return *st;
+}
+
 Global::Global()
 {
-    const char* e = getenv("SRCNN_MAX_WORKSPACE_MB");
-    const size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 16384;
-    ws_budget.store(std::max<size_t>(mb, 1) << 20);
-    auto flag = [](const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; };
-    const char* sel = getenv("SRCNN_CONV12");
-    conv12_valu = sel && strcmp(sel, "valu") == 0;
-    const char* var = getenv("SRCNN_CONV12_VARIANT");
-    conv12_variant = var ? atoi(var) : 1;
-    f16_unfused = flag("SRCNN_F16_UNFUSED");
-    resample_two_pass = flag("SRCNN_RESAMPLE_2PASS");
-    resample_old2d = flag("SRCNN_RESAMPLE_OLD2D");
-    shell_unfused = flag("SRCNN_SHELL_UNFUSED");
-    const char* nu = getenv("SRCNN_NUMA");
-    numa = !(nu && atoi(nu) == 0);
-    if (const char* ml = getenv("SRCNN_MAX_LANES")) max_lanes = (size_t)std::min(64, std::max(1, atoi(ml)));
+    const Settings& st = settings();
+    ws_budget.store((size_t)st.max_workspace_mb << 20);
+    max_lanes = (size_t)st.max_lanes;
 }
 
 // Never destroyed: at process exit the HIP runtime may already be gone when static destructors run, and the
@@ -217,7 +256,6 @@ int make_context_locked(int device)
     build_dev_weights(*dw);
     HIP_TRY(upload_weights(*dw));
     HIP_TRY(conv12_mfma_prepare());
-    HIP_TRY(conv12_f16_prepare());
     auto fw = std::make_unique<FusedF16Weights>();
     build_fused_f16_weights(*dw, *fw);
     HIP_TRY(hipMalloc((void**)&cx->fused_w, sizeof(FusedF16Weights)));
@@ -252,9 +290,9 @@ int make_context_locked(int device)
 int lazy_init_locked()
 {
     if (!G.ctxs.empty()) return SRCNN_OK;
-    const char* env = getenv("SRCNN_DEVICES");
+    const char* env = settings().devices.c_str();
     std::vector<int> devs;
-    if (env && *env) {
+    if (*env) {
         if (strcmp(env, "all") == 0) {
             int n = 0;
             if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
@@ -406,7 +444,7 @@ bool pinned_by_library(const void* p, size_t n)
 void* pinned_alloc(Ctx& cx, size_t bytes)
 {
     void* p = nullptr;
-    const bool want_place = G.numa && cx.numa_node >= 0 && cx.numa_node < 1024;
+    const bool want_place = settings().numa && cx.numa_node >= 0 && cx.numa_node < 1024;
     constexpr unsigned long kMaxNode = 1024;
     unsigned long mask[kMaxNode / (8 * sizeof(unsigned long))] = {0};
     // The policy is the CALLING thread's (an application thread inside ProcessSRCNN): whatever it was -- numactl --membind /
@@ -464,11 +502,7 @@ hipError_t poll_until_ready(Q&& query)
     if (slack > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack);
     return r;
 }
-bool spin_waits()
-{
-    static const bool on = [] { const char* e = getenv("SRCNN_SPIN_WAIT"); return e && atoi(e) != 0; }();
-    return on;
-}
+bool spin_waits() { return settings().spin_wait; }
 }  // namespace
 
 hipError_t wait_event(hipEvent_t e, std::mutex* query_guard)
@@ -633,26 +667,22 @@ void drain_spans_locked(Ctx& cx)
 void run_conv12(const Call& c, const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane, int row0,
                 int rows)
 {
-    if (c.mode == SRCNN_MODE_FAST_F16) launch_conv12_f16(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.cx->num_cus, c.s);
-    else if (G.conv12_valu && (c.relax() & 3) % 3 == 0) launch_conv12(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.strict(), c.s);
-    else {
-        unsigned long long* clk = nullptr;
-        if (G.clock_probe.load(std::memory_order_relaxed) && c.cx->clock_buf)
-            clk = c.cx->clock_buf + 2 * (size_t)(c.cx->clock_n.fetch_add(1) % kClockSlots);
-        // the tile queue lives with the workspace: one per stream, so launches that share it are ordered
-        unsigned* queue = nullptr;
-        if (c.ws) {
-            if (!c.ws->queue && !c.ws->frozen) {
-                void* q = nullptr;
-                // zeroed ON THE LAUNCH STREAM: lane streams are non-blocking, so a null-stream hipMemset is not ordered before
-                // the first kernel that draws from the queue (seen as wrong tiles in the first call of a fresh lane)
-                if (hipMalloc(&q, 2 * sizeof(unsigned)) == hipSuccess && hipMemsetAsync(q, 0, 2 * sizeof(unsigned), c.s) == hipSuccess) c.ws->queue = static_cast<unsigned*>(q);
-                else { (void)hipFree(q); (void)hipGetLastError(); }
-            }
-            queue = c.ws->queue;
+    unsigned long long* clk = nullptr;
+    if (G.clock_probe.load(std::memory_order_relaxed) && c.cx->clock_buf)
+        clk = c.cx->clock_buf + 2 * (size_t)(c.cx->clock_n.fetch_add(1) % kClockSlots);
+    // the tile queue lives with the workspace: one per stream, so launches that share it are ordered
+    unsigned* queue = nullptr;
+    if (c.ws && settings().conv12_queue) {
+        if (!c.ws->queue && !c.ws->frozen) {
+            void* q = nullptr;
+            // zeroed ON THE LAUNCH STREAM: lane streams are non-blocking, so a null-stream hipMemset is not ordered before
+            // the first kernel that draws from the queue (seen as wrong tiles in the first call of a fresh lane)
+            if (hipMalloc(&q, 2 * sizeof(unsigned)) == hipSuccess && hipMemsetAsync(q, 0, 2 * sizeof(unsigned), c.s) == hipSuccess) c.ws->queue = static_cast<unsigned*>(q);
+            else { (void)hipFree(q); (void)hipGetLastError(); }
         }
-        launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.relax(), c.cx->num_cus, G.conv12_variant, c.s, clk, queue);
+        queue = c.ws->queue;
     }
+    launch_conv12_mfma(Y, W, H, y_row_base, y_rows, C2, plane, row0, rows, c.relax(), c.cx->num_cus, c.s, clk, queue);
 }
 
 DevAxisTable view_of(const TableRef& t) { return t->view(); }
@@ -681,7 +711,7 @@ int resample_src_rows(Call& c, const YSource& src, unsigned sw, unsigned sh, uns
         // up-scale in both axes: vertical first, then horizontal (src/frawscale.cpp:238-278), both in one kernel
         if ((rc = get_table(c, filter, dw, sw, th))) return rc;
         if ((rc = get_table(c, filter, dh, sh, tv))) return rc;
-        if (!G.resample_two_pass && !G.resample_old2d &&
+        if (!settings().resample_2pass &&
             launch_rs2d(src, sw, sh, d_dst, dw, dh, r0, r1 - r0, view_of(tv), view_of(th), s)) return SRCNN_OK;
     }
     if (!d_in) return fail(SRCNN_E_UNSUPPORTED, "this resample shape needs a float source plane");
@@ -716,7 +746,6 @@ int resample_src_rows(Call& c, const YSource& src, unsigned sw, unsigned sh, uns
         const float* mid = d_in + (size_t)r0 * sw;
         if (sh != dh) {
             if (!tv && (rc = get_table(c, filter, dh, sh, tv))) return rc;
-            if (!G.resample_two_pass && launch_resample_2d(d_in, sw, sh, d_dst, dw, dh, r0, r1 - r0, view_of(tv), view_of(th), s)) return SRCNN_OK;
             if ((rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)sw * (r1 - r0)))) return rc;
             launch_resample_cols(d_in, sw, 0, ws.tmp, r0, r1 - r0, view_of(tv), s);
             mid = ws.tmp;
@@ -756,7 +785,7 @@ int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw
     const unsigned ua = ca >= 4 ? ca - 4 : 0, ub = std::min(dh, cb + 4);
     int rc;
     if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
-    const bool fused = c.mode == SRCNN_MODE_FAST_F16 && !G.f16_unfused;
+    const bool fused = c.mode == SRCNN_MODE_FAST_F16;
     if (fused) {
         // non-parity tier: one kernel for all three layers, no layer-2 planes at all
         {
@@ -865,7 +894,7 @@ int y_path_range(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw
     const size_t budget = G.ws_budget.load();
     if (r1 > dh || r0 >= r1) return fail(SRCNN_E_ARG, "row range [%u,%u) outside 0..%u", r0, r1, dh);
     const size_t row_bytes = (size_t)C2N * dw * sizeof(float);
-    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !G.f16_unfused;      // the fused kernel has no layer-2 planes
+    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16;      // the fused kernel has no layer-2 planes
     const YSource src = YSource::from_plane(d_in);
     if (no_planes || row_bytes * ((size_t)(r1 - r0) + 4) <= budget) return y_path_rows(c, src, w, h, dw, dh, filter, r0, r1, d_out);
     const unsigned band = budget_band_rows(dw);
@@ -1499,6 +1528,15 @@ int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, un
     launch_fused_f16(d_up, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, cx->fused_w, cx->num_cus, (hipStream_t)stream, d_dbg);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
+}
+
+// The switches this process runs with (srcnn_settings.hpp): text into buf (NUL-terminated, truncated to cap), returns the
+// length the full text needs.  markdown != 0: the rows of DESIGN.md section 6 (defaults, not current values).  No device needed.
+int srcnn_debug_settings(char* buf, size_t cap, int markdown)
+{
+    const std::string t = settings().describe(markdown != 0);
+    if (buf && cap) snprintf(buf, cap, "%s", t.c_str());
+    return (int)t.size();
 }
 
 // test hook: number of cached contribution tables / of ProcessSRCNN lanes created so far, summed over the contexts

@@ -64,41 +64,52 @@ std::atomic<bool> g_poisoned{false};    // a deadline was missed: the communicat
 //   * device side: wait_stream_deadline() -- a polled wait for everything queued on a stream, used by srcnn_comm_barrier and
 //     srcnn_comm_wait; on a miss it aborts the communicator the same way, which also ends the spinning kernels.
 // SRCNN_COMM_TIMEOUT_MS / srcnn_comm_set_timeout_ms: default 60 s; 0 = wait for ever (the round-3 behaviour).
-std::atomic<int> g_timeout_ms{[] { const char* e = getenv("SRCNN_COMM_TIMEOUT_MS"); return e ? std::max(0, atoi(e)) : 60000; }()};
+std::atomic<int> g_timeout_ms{(int)srcnn::settings().comm_timeout_ms};
 
-void abort_comm(ncclComm_t comm)
+// Communicator generation: bumped by every init and destroy.  An abort carries the generation of the communicator it was
+// armed for and is ignored when that communicator is gone (a destroy + init on another thread must not get the new one
+// aborted, and the freed one must not be touched again).  g_abort_mu is held while ncclCommAbort runs; srcnn_comm_destroy takes
+// it too, so a destroy never runs ncclCommDestroy beside an abort of the same communicator.
+std::atomic<unsigned> g_gen{0};
+std::mutex g_abort_mu;
+bool g_abort_called = false;            // under g_abort_mu: ncclCommAbort ran for the current generation
+
+void abort_comm(ncclComm_t comm, unsigned gen)
 {
-    if (g_poisoned.exchange(true)) return;               // once: the abort destroys the communicator
+    std::lock_guard<std::mutex> lk(g_abort_mu);
+    if (gen != g_gen.load() || g_abort_called) return;
+    g_poisoned = true;
+    g_abort_called = true;
     (void)hipSetDevice(g_device);                          // (the watchdog's own thread has never bound a device)
     if (R.CommAbort && comm) (void)R.CommAbort(comm);
 }
 
 class Watchdog {
 public:
-    // arm() .. disarm() brackets one blocking call; returns through `fired` whether the deadline hit
-    // One armed region at a time: a second thread's RCCL call waits here until the first has returned (or its deadline has
-    // aborted the communicator) -- the regions are the host-side queueing calls, microseconds long unless a peer is missing.
-    void arm(ncclComm_t comm)
+    // arm() .. disarm() brackets one blocking call.  arm() returns whether a deadline is running -- the caller hands that back to
+    // disarm(), so a thread whose arm() was a no-op (no deadline configured at that moment) never touches another thread's
+    // region.  One armed region at a time: a second thread's RCCL call waits in arm() until the first has returned (or its
+    // deadline has aborted the communicator) -- the regions are host-side queueing calls, microseconds long unless a peer is missing.
+    bool arm(ncclComm_t comm, unsigned gen)
     {
         const int ms = g_timeout_ms.load();
-        if (ms <= 0) return;
+        if (ms <= 0) return false;
         region_.lock();
-        owner_armed_ = true;
         std::lock_guard<std::mutex> lk(m_);
         if (!started_) { th_ = std::thread([this] { run(); }); th_.detach(); started_ = true; }
-        comm_ = comm; fired_ = false; armed_ = true;
+        comm_ = comm; gen_ = gen; fired_ = false; armed_ = true;
         deadline_ = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
         cv_.notify_all();
+        return true;
     }
-    bool disarm()
+    bool disarm(bool armed)                   // true: the deadline hit (the communicator is poisoned and being aborted)
     {
+        if (!armed) return false;
         bool fired;
         {
             std::lock_guard<std::mutex> lk(m_);
-            if (!owner_armed_) return false;         // arm() was a no-op (no deadline configured)
             armed_ = false;
             fired = fired_;
-            owner_armed_ = false;
             cv_.notify_all();
         }
         region_.unlock();
@@ -113,9 +124,13 @@ private:
             while (armed_ && cv_.wait_until(lk, deadline_) != std::cv_status::timeout) {}
             if (armed_ && std::chrono::steady_clock::now() >= deadline_) {
                 fired_ = true; armed_ = false;
-                ncclComm_t c = comm_;
+                const ncclComm_t c = comm_;
+                const unsigned gen = gen_;
+                // poisoned BEFORE m_ is dropped: an owner whose RCCL call returns right now sees fired_ under m_ and, whatever it
+                // calls next, a poisoned communicator -- never a healthy-looking one with an abort about to start
+                if (gen == g_gen.load()) g_poisoned = true;
                 lk.unlock();
-                abort_comm(c);
+                abort_comm(c, gen);
                 lk.lock();
             }
         }
@@ -123,14 +138,15 @@ private:
     std::mutex m_, region_;
     std::condition_variable cv_;
     std::thread th_;
-    bool started_ = false, armed_ = false, fired_ = false, owner_armed_ = false;
+    bool started_ = false, armed_ = false, fired_ = false;
     ncclComm_t comm_ = nullptr;
+    unsigned gen_ = 0;
     std::chrono::steady_clock::time_point deadline_;
 };
 Watchdog& watchdog() { static Watchdog* w = new Watchdog; return *w; }      // (never destroyed: its thread outlives main)
 
 // everything queued on `s` has completed, or the deadline passed (then the communicator is aborted): hipSuccess / hipErrorNotReady
-hipError_t wait_stream_deadline(hipStream_t s, ncclComm_t comm)
+hipError_t wait_stream_deadline(hipStream_t s, ncclComm_t comm, unsigned gen)
 {
     const int ms = g_timeout_ms.load();
     if (ms <= 0) return srcnn::wait_stream(s);
@@ -138,19 +154,26 @@ hipError_t wait_stream_deadline(hipStream_t s, ncclComm_t comm)
     for (int n = 0;; ++n) {
         const hipError_t e = hipStreamQuery(s);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() >= deadline) { abort_comm(comm); return hipErrorNotReady; }
+        if (std::chrono::steady_clock::now() >= deadline) { abort_comm(comm, gen); return hipErrorNotReady; }
         if (n > 64) std::this_thread::sleep_for(std::chrono::microseconds(n < 2000 ? 50 : 500));
     }
 }
 
 // A consistent view of the communicator for one call (taken under g_mu; the collective itself runs outside it so that a
 // rank blocked in RCCL never blocks srcnn_comm_rank on another thread).
-struct CommView { ncclComm_t comm; int rank, nranks, device; };
+struct CommView { ncclComm_t comm; int rank, nranks, device; unsigned gen; };
 bool view(CommView& v)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    v = CommView{g_comm, g_rank, g_nranks, g_device};
+    v = CommView{g_comm, g_rank, g_nranks, g_device, g_gen.load()};
     return v.comm != nullptr;
+}
+// the streams communication was queued on since init (bounded; what srcnn_comm_destroy drains under the deadline)
+std::vector<hipStream_t> g_streams;
+void note_stream(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (std::find(g_streams.begin(), g_streams.end(), s) == g_streams.end() && g_streams.size() < 64) g_streams.push_back(s);
 }
 thread_local char g_cerr[256];
 
@@ -164,6 +187,16 @@ int load()
     // take the librccl that lives next to it, by absolute path; only then fall back to the loader's search.
     void* h = nullptr;
     Dl_info info;
+    // SRCNN_RCCL_LIB: an explicit library, consulted first and alone (a site build of RCCL; the test-suite's stand-in that
+    // moves data between processes sharing ONE device, tests/rccl_double/ -- the installed RCCL refuses two ranks per device)
+    if (const char* path = srcnn::settings().rccl_lib.empty() ? nullptr : srcnn::settings().rccl_lib.c_str()) {
+        h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            snprintf(g_cerr, sizeof g_cerr, "dlopen(SRCNN_RCCL_LIB=%s) failed: %s", path, dlerror());
+            srcnn::set_last_error(g_cerr);
+            return SRCNN_E_COMM;
+        }
+    } else
     if (dladdr(reinterpret_cast<void*>(&hipFree), &info) && info.dli_fname) {
         std::string dir(info.dli_fname);
         const size_t slash = dir.rfind('/');
@@ -175,8 +208,7 @@ int load()
             }
         }
     }
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
     if (!h) {
         snprintf(g_cerr, sizeof g_cerr, "dlopen(librccl) failed: %s", dlerror());
         srcnn::set_last_error(g_cerr);
@@ -233,6 +265,7 @@ unsigned long long fnv1a(const void* p, size_t n, unsigned long long h = 1469598
 }  // namespace
 
 namespace srcnn {
+constexpr int kTiledPlanGrid = 512, kTiledPlanTileRows = 16;
 std::vector<unsigned> tiled_cuts(unsigned out_w, unsigned out_h, int rank, int nranks, int npieces)
 {
     unsigned b0 = 0, bn = 0;
@@ -248,9 +281,9 @@ std::vector<unsigned> tiled_cuts(unsigned out_w, unsigned out_h, int rank, int n
     std::vector<double> frac((size_t)npieces - 1);
     const double total = 0.5 * npieces * (npieces + 1);
     for (int i = 0; i + 1 < npieces; ++i) frac[i] = (double)(npieces - i) / total;
-    int grid = 0, tile_rows = 0;
-    conv12_grid_info(256, G.conv12_variant, &grid, &tile_rows);
-    if (G.conv12_valu) grid = 0;
+    // ... nor on any switch of this process: the production layer-1+2 geometry (2 workgroups x 256 CUs, 16-row tiles) is
+    // written down here, so ranks started with different SRCNN_* environments still derive the same gather table.
+    constexpr int grid = kTiledPlanGrid, tile_rows = kTiledPlanTileRows;
     return plan_cuts(b0, b0 + bn, out_w, out_h, frac.data(), npieces - 1, grid, tile_rows);
 }
 }  // namespace srcnn
@@ -290,10 +323,16 @@ int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int n
         return SRCNN_E_DEVMEM;
     }
     if (hipMalloc((void**)&g_check, 2 * sizeof(unsigned long long)) != hipSuccess) g_check = nullptr;    // SRCNN_COMM_CHECK only
+    {
+        std::lock_guard<std::mutex> ak(g_abort_mu);
+        ++g_gen;
+        g_abort_called = false;
+        g_poisoned = false;
+    }
     g_comm = comm; g_token = token;
     g_rank = rank; g_nranks = nranks; g_device = cx->device;
-    g_poisoned = false;
     g_verified.clear();
+    g_streams.clear();
     return SRCNN_OK;
 }
 
@@ -302,22 +341,48 @@ int srcnn_comm_destroy(void)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_comm) return SRCNN_OK;
     (void)hipSetDevice(g_device);
-    if (g_poisoned.load() && R.CommAbort) {
-        // aborted after a missed deadline: ncclCommAbort has already ended its kernels and freed the communicator
-    } else if (g_poisoned.load()) {
-        // (a librccl without ncclCommAbort: nothing was aborted; do not wait for peers that are gone -- the object is leaked)
-    } else {
-        hipDeviceSynchronize();
-        R.CommDestroy(g_comm);
+    {
+        // an abort in flight (watchdog thread, or another thread's missed srcnn_comm_wait) finishes first; from here on aborts
+        // armed for this communicator are stale and ignored
+        std::lock_guard<std::mutex> ak(g_abort_mu);
+        ++g_gen;
+        bool drained = true;
+        if (!g_poisoned.load()) {
+            // A healthy communicator may still have sends / receives queued whose peer died after this rank's call returned: the
+            // drain is bounded like every other wait on a peer (a bare hipDeviceSynchronize hung here for ever).  On a miss the
+            // communicator is aborted -- which ends the spinning kernels -- instead of destroyed.
+            const int ms = g_timeout_ms.load();
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
+            std::vector<hipStream_t> streams = g_streams;
+            if (g_comm_stream) streams.push_back(g_comm_stream);
+            for (hipStream_t st : streams) {
+                for (int n = 0; drained; ++n) {
+                    const hipError_t e = hipStreamQuery(st);
+                    if (e != hipErrorNotReady) break;                  // drained (or the stream is gone / in error: nothing to wait for)
+                    if (ms > 0 && std::chrono::steady_clock::now() >= deadline) { drained = false; break; }
+                    if (n > 64) std::this_thread::sleep_for(std::chrono::microseconds(n < 2000 ? 50 : 500));
+                }
+            }
+        }
+        if (g_abort_called) {
+            // aborted after a missed deadline: ncclCommAbort has already ended its kernels and freed the communicator
+        } else if (!drained || g_poisoned.load()) {
+            // (a librccl without ncclCommAbort leaks the object rather than wait for peers that are gone)
+            if (R.CommAbort) (void)R.CommAbort(g_comm);
+        } else {
+            R.CommDestroy(g_comm);
+        }
+        g_abort_called = false;
+        g_poisoned = false;
     }
     g_comm = nullptr;
     hipFree(g_token); g_token = nullptr;
     hipFree(g_check); g_check = nullptr;
-    g_poisoned = false;
     for (auto e : g_events) (void)hipEventDestroy(e);
     g_events.clear();
     if (g_comm_stream) (void)hipStreamDestroy(g_comm_stream);
     g_comm_stream = nullptr;
+    g_streams.clear();
     g_rank = 0; g_nranks = 1;
     return SRCNN_OK;
 }
@@ -332,13 +397,13 @@ int srcnn_comm_rank(int* rank, int* nranks)
 }
 
 namespace {
-// SRCNN_COMM_CHECK=1: before a gather trusts a counts / offsets table, every rank contributes the table's checksum to a
-// min/max all-reduce; ranks that derived different tables (which would otherwise pair a send with a receive of another size
-// and hang or corrupt) all return SRCNN_E_COMM instead.  A table that was seen to agree is not checked again.
+// Before a gather trusts a counts / offsets table, every rank contributes the table's checksum to a min/max all-reduce; ranks
+// that derived different tables (which would otherwise pair a send with a receive of another size and hang or corrupt) all
+// return SRCNN_E_COMM instead.  A table that was seen to agree is not checked again, so a steady stream of frames of one
+// geometry pays 16 bytes of all-reduce per piece once.  On by default since round 5; SRCNN_COMM_CHECK=0 skips it.
 int verify_table(const CommView& v, unsigned long long h, hipStream_t s)
 {
-    static const bool on = [] { const char* e = getenv("SRCNN_COMM_CHECK"); return e && atoi(e) != 0; }();
-    if (!on) return SRCNN_OK;
+    if (!srcnn::settings().comm_check) return SRCNN_OK;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (std::find(g_verified.begin(), g_verified.end(), h) != g_verified.end()) return SRCNN_OK;
@@ -346,11 +411,11 @@ int verify_table(const CommView& v, unsigned long long h, hipStream_t s)
     }
     unsigned long long words[2] = {h, ~h};                   // min(h) and min(~h) = ~max(h)
     if (hipMemcpyAsync(g_check, words, sizeof words, hipMemcpyHostToDevice, s) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: upload failed");
-    watchdog().arm(v.comm);
+    const bool armed = watchdog().arm(v.comm, v.gen);
     const ncclResult_t r = R.AllReduce(g_check, g_check, 2, ncclUint64, ncclMin, v.comm, s);
-    const bool late = watchdog().disarm();
+    const bool late = watchdog().disarm(armed);
     if (late || r != ncclSuccess) return comm_fail(late ? "SRCNN_COMM_CHECK: all-reduce missed its deadline" : "SRCNN_COMM_CHECK: all-reduce failed");
-    if (wait_stream_deadline(s, v.comm) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: a rank never arrived (deadline)");
+    if (wait_stream_deadline(s, v.comm, v.gen) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: a rank never arrived (deadline)");
     if (hipMemcpy(words, g_check, sizeof words, hipMemcpyDeviceToHost) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: read-back failed");
     if (words[0] != ~words[1]) {
         snprintf(g_cerr, sizeof g_cerr, "SRCNN_COMM_CHECK: the ranks disagree about the gather table (this rank %016llx, min %016llx, max %016llx)",
@@ -392,7 +457,8 @@ int srcnn_comm_gatherv_at_f32(const float* d_send, const size_t* counts, const s
     // every Send/Recv of the group is attempted and GroupEnd always runs, so a failure never leaves the group open
     ncclResult_t first_bad = ncclSuccess;
     auto note = [&](ncclResult_t r) { if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r; };
-    watchdog().arm(v.comm);
+    note_stream(s);
+    const bool armed = watchdog().arm(v.comm, v.gen);
     note(R.GroupStart());
     if (v.rank == root) {
         for (int r = 0; r < v.nranks; ++r)
@@ -401,7 +467,7 @@ int srcnn_comm_gatherv_at_f32(const float* d_send, const size_t* counts, const s
         note(R.Send(d_send, counts[v.rank], ncclFloat, root, v.comm, s));
     }
     note(R.GroupEnd());
-    if (watchdog().disarm()) return comm_fail("band gather: a peer did not arrive before the deadline (SRCNN_COMM_TIMEOUT_MS); communicator aborted");
+    if (watchdog().disarm(armed)) return comm_fail("band gather: a peer did not arrive before the deadline (SRCNN_COMM_TIMEOUT_MS); communicator aborted");
     if (first_bad != ncclSuccess) {
         snprintf(g_cerr, sizeof g_cerr, "band gather failed: %s", R.GetErrorString(first_bad));
         srcnn::set_last_error(g_cerr);
@@ -525,9 +591,10 @@ int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, v
     if (!view(v)) return comm_fail("no communicator");
     if (g_poisoned.load()) return poisoned_fail();
     if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
-    watchdog().arm(v.comm);
+    note_stream((hipStream_t)stream);
+    const bool armed = watchdog().arm(v.comm, v.gen);
     const ncclResult_t r = R.AllGather(d_send, d_recv, count, ncclFloat, v.comm, (hipStream_t)stream);
-    if (watchdog().disarm()) return comm_fail("all-gather: deadline missed while queueing; communicator aborted");
+    if (watchdog().disarm(armed)) return comm_fail("all-gather: deadline missed while queueing; communicator aborted");
     NCCL_TRY(r);
     return SRCNN_OK;
 }
@@ -538,9 +605,10 @@ int srcnn_comm_barrier(void* stream)
     if (!view(v)) return comm_fail("no communicator");
     if (g_poisoned.load()) return poisoned_fail();
     if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
-    watchdog().arm(v.comm);
+    note_stream((hipStream_t)stream);
+    const bool armed = watchdog().arm(v.comm, v.gen);
     const ncclResult_t r = R.AllReduce(g_token, g_token, 1, ncclFloat, ncclSum, v.comm, (hipStream_t)stream);
-    if (watchdog().disarm()) return comm_fail("barrier: deadline missed while queueing; communicator aborted");
+    if (watchdog().disarm(armed)) return comm_fail("barrier: deadline missed while queueing; communicator aborted");
     NCCL_TRY(r);
     return srcnn_comm_wait(stream);
 }
@@ -554,7 +622,7 @@ int srcnn_comm_wait(void* stream)
     CommView v;
     if (!view(v)) return comm_fail("no communicator");
     if (hipSetDevice(v.device) != hipSuccess) return comm_fail("hipSetDevice failed");
-    const hipError_t e = wait_stream_deadline((hipStream_t)stream, v.comm);
+    const hipError_t e = wait_stream_deadline((hipStream_t)stream, v.comm, v.gen);
     if (e == hipErrorNotReady)
         return comm_fail("srcnn_comm_wait: the stream did not drain before the deadline (SRCNN_COMM_TIMEOUT_MS): a peer is missing or the ranks "
                          "disagree about a gather; communicator aborted");

@@ -24,6 +24,7 @@
 
 #include "../../include/srcnn_amd.h"
 #include "srcnn_kernels.h"
+#include "srcnn_settings.hpp"
 
 namespace srcnn {
 
@@ -188,13 +189,6 @@ struct Global {
     std::atomic<int> mode{SRCNN_MODE_STRICT};        // as Call::mode (tier in the low byte, relaxation mask above it)
     std::atomic<unsigned> relax_mask{SRCNN_RELAX_L3_X64};   // what SRCNN_MODE_RELAXED relaxes (srcnn_set_relaxation)
     std::atomic<size_t> ws_budget;
-    int conv12_variant = 1;     // SRCNN_CONV12_VARIANT: see launch_conv12_mfma
-    bool conv12_valu = false;   // SRCNN_CONV12=valu selects the VALU-only layer-1+2 kernel (A/B testing)
-    bool resample_two_pass = false;   // SRCNN_RESAMPLE_2PASS=1: always the two separate resampler passes (A/B testing)
-    bool resample_old2d = false;      // SRCNN_RESAMPLE_OLD2D=1: the round-2 one-launch kernel instead of k_rs2d (A/B testing)
-    bool shell_unfused = false;       // SRCNN_SHELL_UNFUSED=1: colour shell as split + plane resamples + merge (A/B testing)
-    bool f16_unfused = false;   // SRCNN_F16_UNFUSED=1: FAST_F16 as k_conv12_f16 + k_conv3_fast (A/B testing)
-    bool numa = true;           // SRCNN_NUMA=0: do not place page-locked staging on the device's NUMA node
     size_t max_lanes = kDefaultMaxLanes;   // concurrent ProcessSRCNN calls per context before callers queue
     Global();
 };

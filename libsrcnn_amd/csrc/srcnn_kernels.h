@@ -106,23 +106,15 @@ bool rs2d_fits(int np, int src_w, int src_h, int dst_w, int dst_h, int r0, int r
 bool launch_merge_fused(const unsigned char* rgb_src, int src_w, int src_h, int depth, const float* Yp,
                         unsigned char* rgb_out, unsigned char* conv_opt, int dst_w, int dst_h, int dst_row0, int dst_rows,
                         const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s);
-// both passes of an up-scale in one kernel (round 2); returns false (nothing launched) when the shape does not qualify
-bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
-                        const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s);
-void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                   int out_rows, bool strict, hipStream_t s);
 hipError_t conv12_mfma_prepare();
-// relax: RELAX_L1 | RELAX_L2 bits (0 = strict); the single-layer forms always take the production geometry (variant 1)
+// relax: RELAX_L1 | RELAX_L2 bits (0 = strict)
 // clk: NULL, or two device words that receive (shader-clock cycles, 100 MHz ticks) of workgroup 0's lifetime
 // queue: NULL (tiles dealt with a static stride), or two zeroed device words owned by the launch stream's workspace: the tile
-//        queue of the production kernel (it leaves them zeroed again); SRCNN_CONV12_QUEUE=0 ignores it (A/B runs)
+//        queue of the kernel (it leaves them zeroed again)
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                        int out_rows, int relax, int num_cus, int variant, hipStream_t s, unsigned long long* clk = nullptr,
+                        int out_rows, int relax, int num_cus, hipStream_t s, unsigned long long* clk = nullptr,
                         unsigned* queue = nullptr);
-void conv12_grid_info(int num_cus, int variant, int* blocks, int* tile_rows);
-hipError_t conv12_f16_prepare();
-void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                       int out_rows, int num_cus, hipStream_t s);
+void conv12_grid_info(int num_cus, int* blocks, int* tile_rows);
 // relax: RELAX_L3_X64 / RELAX_L3_F32 bits (neither = strict)
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
                   int out_row0, int out_rows, int relax, hipStream_t s);

@@ -1,11 +1,12 @@
 // srcnn_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the SRCNN Y path.
 //
 // Reference behaviour reproduced (rageworx/libsrcnn, paths relative to its tree):
-//   k_resample_cols/rows  FRAWResizeEngine::verticalFilter / horizontalFilter   src/frawscale.cpp:288-385
-//   k_conv12_mfma         64 x convolution99 + 32 x convolution11  (production)  src/libsrcnn.cpp:350-447
-//   k_conv12              the same on the VALU only (A/B alternative, SRCNN_CONV12=valu)
-//   k_conv12_f16          the same as split-fp16 GEMMs (non-parity tier SRCNN_MODE_FAST_F16)
+//   k_rs2d_dma / k_rs2d   FRAWResizeEngine::scale for up-scales, both passes in one kernel  src/frawscale.cpp:238-385
+//   k_resample_cols/rows  verticalFilter / horizontalFilter, generic (down-scales, long tables)   src/frawscale.cpp:288-385
+//   k_conv12_mfma         64 x convolution99 + 32 x convolution11                src/libsrcnn.cpp:350-447
 //   k_conv3               convolution55                                          src/libsrcnn.cpp:449-529
+// (round 5: one production form and one fallback per kernel -- the A/B geometries of rounds 1-4, the VALU-only layer-1+2
+//  kernel, the round-2 resamplers and the unfused fp16 tier are gone; their measurements stay in docs/HISTORY.md)
 //   k_conv1/2_planes      the two layers unfused, 64 / 32 planes in HBM (stage-level parity entry points)
 //   k_rgb_split / k_ycc_merge  colour shell                                      src/libsrcnn.cpp:233-308,889-905
 //
@@ -27,6 +28,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "srcnn_kernels.h"
+#include "srcnn_settings.hpp"
 
 #pragma clang fp contract(off)
 
@@ -37,13 +39,6 @@ __constant__ DevWeights cW;
 hipError_t upload_weights(const DevWeights& w)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(cW), &w, sizeof(DevWeights));
-}
-
-template <bool STRICT>
-__device__ __forceinline__ float mac(float acc, float a, float b)
-{
-    if constexpr (STRICT) return acc + a * b;          // v_mul_f32 ; v_add_f32 (contract off)
-    else return __builtin_fmaf(a, b, acc);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -87,114 +82,6 @@ __global__ __launch_bounds__(256) void k_resample_rows(   // horizontal pass: [r
         double acc = 0.0;
         for (int t = 0; t < n; ++t) acc = acc + wr[t] * (double)in[t];
         dst[(size_t)y * dst_w + x] = (float)acc;
-    }
-}
-
-// Same pass for tables with at most RS_MAXT taps (every up-scale with the five filters): a thread keeps the
-// weights of its output column in registers and walks RS_RPT rows, so the per-column table is read once per
-// RS_RPT rows instead of once per pixel (the table, not the image, was the dominant traffic).
-constexpr int RS_MAXT = 8, RS_RPT = 8;
-__global__ __launch_bounds__(256) void k_resample_rows_reg(
-    const float* __restrict__ src, int src_w, float* __restrict__ dst, int dst_w, int rows,
-    const int* __restrict__ first, const int* __restrict__ taps, const double* __restrict__ wt, int stride)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= dst_w) return;
-    const int s0 = first[x], n = taps[x];
-    const double* wr = wt + (size_t)x * stride;
-    double w[RS_MAXT];
-#pragma unroll
-    for (int t = 0; t < RS_MAXT; ++t) w[t] = t < n ? wr[t] : 0.0;
-    for (int yb = blockIdx.y * RS_RPT; yb < rows; yb += gridDim.y * RS_RPT)
-    for (int y = yb; y < min(yb + RS_RPT, rows); ++y) {
-        const float* in = src + (size_t)y * src_w + s0;
-        double acc = 0.0;
-#pragma unroll
-        for (int t = 0; t < RS_MAXT; ++t)
-            if (t < n) acc = acc + w[t] * (double)in[t];     // same taps, same order as the generic kernel
-        dst[(size_t)y * dst_w + x] = (float)acc;
-    }
-}
-
-// Both passes of an up-scale in ONE kernel (vertical first, then horizontal, as src/frawscale.cpp:238-278 orders them):
-// a block owns an R2_TH x R2_TW output tile, runs the vertical pass for exactly the intermediate columns the tile's
-// horizontal taps touch into LDS (fp32, i.e. rounded after the pass like the reference's intermediate image) and then the
-// horizontal pass out of LDS.  Same operations in the same order as k_resample_cols + k_resample_rows_reg -- the
-// intermediate image just never goes to HBM (one launch instead of two, no dst_h x src_w round trip).
-constexpr int R2_TW = 256, R2_TH = 8, R2_LW = R2_TW + 24;       // LDS row: the tile's source-column span (<= TW + taps)
-constexpr int R2_SR = R2_TH + RS_MAXT;                          // source rows a tile's vertical taps can touch (up-scale)
-__global__ __launch_bounds__(R2_TW) void k_resample_2d(
-    const float* __restrict__ src, int src_w, float* __restrict__ dst, int dst_w, int dst_row0, int dst_rows,
-    const int* __restrict__ vfirst, const int* __restrict__ vtaps, const double* __restrict__ vwt, int vstride,
-    const int* __restrict__ hfirst, const int* __restrict__ htaps, const double* __restrict__ hwt, int hstride)
-{
-    // Every global load of the block is issued in ONE batch (tables, then the source patch); the two passes then run
-    // out of LDS.  (A first version read its sources row by row behind dependent table loads and was latency-bound.)
-    __shared__ float raw[R2_SR][R2_LW];       // source patch: rows [vmin, vmax) x columns [c0, c0+cn)
-    __shared__ float mid[R2_TH][R2_LW];       // after the vertical pass (fp32, like the reference's intermediate image)
-    __shared__ double vw[R2_TH][RS_MAXT];
-    __shared__ int vf[R2_TH], vn[R2_TH];
-    __shared__ int span[4];                   // min first_h, max (first_h + taps_h), min first_v, max (first_v + taps_v)
-    const int tid = threadIdx.x;
-    const int x = blockIdx.x * R2_TW + tid;
-    const int xc = min(x, dst_w - 1);
-    const int s0 = hfirst[xc], n = htaps[xc];
-    const int ry0 = blockIdx.y * R2_TH;
-    const int rows = min(R2_TH, dst_rows - ry0);
-    if (tid == 0) { span[0] = 0x7fffffff; span[1] = 0; span[2] = 0x7fffffff; span[3] = 0; }
-    __syncthreads();
-    if (tid < R2_TH * RS_MAXT) {
-        const int r = tid / RS_MAXT, t = tid - r * RS_MAXT;
-        if (r < rows) {
-            const int y = dst_row0 + ry0 + r;
-            const int cnt = vtaps[y];
-            vw[r][t] = t < cnt ? vwt[(size_t)y * vstride + t] : 0.0;
-            if (t == 0) {
-                const int f = vfirst[y];
-                vf[r] = f; vn[r] = cnt;
-                atomicMin(&span[2], f);
-                atomicMax(&span[3], f + cnt);
-            }
-        }
-    }
-    {   // column span of the tile: reduce inside the wave first (256 LDS atomics on one address cost microseconds)
-        int lo = s0, hi = s0 + n;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-        if ((tid & 63) == 0) { atomicMin(&span[0], lo); atomicMax(&span[1], hi); }
-    }
-    // the horizontal weights of this thread's column: independent of everything above, so requested now
-    const double* wr = hwt + (size_t)xc * hstride;
-    double w[RS_MAXT];
-#pragma unroll
-    for (int t = 0; t < RS_MAXT; ++t) w[t] = t < n ? wr[t] : 0.0;
-    __syncthreads();
-    const int c0 = span[0], cn = min(span[1] - c0, R2_LW);       // host guarantees both spans fit (launch_resample_2d)
-    const int vmin = span[2], nsrc = min(span[3] - vmin, R2_SR);
-    for (int r = 0; r < nsrc; ++r) {
-        const float* row = src + (size_t)(vmin + r) * src_w + c0;
-        for (int c = tid; c < cn; c += R2_TW) raw[r][c] = row[c];
-    }
-    __syncthreads();
-    // ---- vertical pass: same products, same order as k_resample_cols ----
-    for (int r = 0; r < rows; ++r) {
-        const int rb = vf[r] - vmin, cnt = vn[r];
-        for (int c = tid; c < cn; c += R2_TW) {
-            double acc = 0.0;
-            for (int t = 0; t < cnt; ++t) acc = acc + vw[r][t] * (double)raw[rb + t][c];
-            mid[r][c] = (float)acc;
-        }
-    }
-    __syncthreads();
-    if (x >= dst_w) return;
-    // ---- horizontal pass: same as k_resample_rows_reg ----
-    for (int r = 0; r < rows; ++r) {
-        const float* in = &mid[r][s0 - c0];
-        double acc = 0.0;
-#pragma unroll
-        for (int t = 0; t < RS_MAXT; ++t)
-            if (t < n) acc = acc + w[t] * (double)in[t];
-        dst[(size_t)(ry0 + r) * dst_w + x] = (float)acc;
     }
 }
 
@@ -683,86 +570,6 @@ __global__ __launch_bounds__(256) void k_rs2d_dma(const Rs2dArgs a)
 }
 
 // =============================================================================================
-// conv12, VALU-only alternative (SRCNN_CONV12=valu; the production kernel is k_conv12_mfma below):
-// 9x9x1->64 + ReLU, then 1x1x64->32 + ReLU, fused; the 64 intermediate planes of the
-// reference never exist.  Lane = PX output pixels of one row (x = tile_x + lane + 64*p); all 64
-// layer-1 accumulators of a pixel live in VGPRs, weights arrive as SGPRs.  The Y tile (+4 halo,
-// clamp-to-edge at the true image border) is staged once in LDS.
-//   VALU work per pixel: (5184 + 2048) x (mul + add);  LDS: 81 b32 reads;  HBM: 4 B in, 128 B out.
-// =============================================================================================
-template <int PX, bool STRICT>
-__global__ __launch_bounds__(256) void k_conv12(
-    const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,   // Y holds rows [y_row_base, +y_rows)
-    float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows)  // writes rows [out_row0, +out_rows)
-{
-    constexpr int TW = 64 * PX;          // tile width  (one wave spans it)
-    constexpr int TH = 4;                // tile height (one row per wave)
-    constexpr int LW = TW + 8;
-    __shared__ float tile[(TH + 8) * LW];
-
-    const int tx0 = blockIdx.x * TW;
-    const int ty0 = out_row0 + blockIdx.y * TH;
-    for (int e = threadIdx.x; e < (TH + 8) * LW; e += 256) {
-        const int r = e / LW, c = e - r * LW;
-        const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c - 4, 0, W - 1);
-        tile[e] = Y[(size_t)(gy - y_row_base) * W + gx];
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int row = ty0 + wv;
-
-    float acc[C1N][PX];
-#pragma unroll
-    for (int k = 0; k < C1N; ++k)
-#pragma unroll
-        for (int p = 0; p < PX; ++p) acc[k][p] = 0.f;
-
-#pragma unroll 1
-    for (int i = 0; i < 9; ++i) {
-        float yv[9][PX];
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-#pragma unroll
-            for (int p = 0; p < PX; ++p) yv[j][p] = tile[(wv + i) * LW + lane + 64 * p + j];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const float* wrow = cW.w1t[i * 9 + j];
-#pragma unroll
-            for (int k = 0; k < C1N; ++k) {
-                const float wk = wrow[k];
-#pragma unroll
-                for (int p = 0; p < PX; ++p) acc[k][p] = mac<STRICT>(acc[k][p], wk, yv[j][p]);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < C1N; ++k)
-#pragma unroll
-        for (int p = 0; p < PX; ++p) acc[k][p] = fmaxf(acc[k][p] + cW.b1[k], 0.f);
-
-    const bool row_ok = (row < out_row0 + out_rows) && (row < H);
-#pragma unroll 2
-    for (int m = 0; m < C2N; ++m) {
-        float a[PX];
-#pragma unroll
-        for (int p = 0; p < PX; ++p) a[p] = 0.f;
-#pragma unroll
-        for (int f = 0; f < C1N; ++f) {
-            const float wf = cW.w2[m][f];
-#pragma unroll
-            for (int p = 0; p < PX; ++p) a[p] = mac<STRICT>(a[p], acc[f][p], wf);
-        }
-        float* dst = C2 + (size_t)m * plane_stride + (size_t)(row - out_row0) * W;
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            const int x = tx0 + lane + 64 * p;
-            if (row_ok && x < W) dst[x] = fmaxf(a[p] + cW.b2[m], 0.f);
-        }
-    }
-}
-
-// =============================================================================================
 // conv12 with exact products from the matrix instruction (the production layer-1+2 kernel).
 //
 // Strict mode may not fuse the multiply into the add, so on the VALU every MAC costs two
@@ -788,30 +595,31 @@ __global__ __launch_bounds__(256) void k_conv12(
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int M_TW = 64;                           // block tile: 2 segments wide, 2*NW rows -> 4 segments per wave
+constexpr int M_NW = 8;                            // waves per workgroup (512 threads; 2 workgroups per CU = 4 waves per SIMD)
+constexpr int M_TW = 64, M_TH = 2 * M_NW;          // block tile 64 x 16: 2 segments wide, 16 rows -> 4 segments per wave
 constexpr int M_LW = M_TW + 8;
 constexpr int M_W1 = 81 * 64, M_W2 = 32 * 64, M_B1 = 64, M_B2 = 32;
 constexpr int M_C1 = 32 * 32;                      // per-wave layer-1 slab: 32 channels x 32 px (one MFMA block at a time)
-constexpr int m_th(int nw) { return 2 * nw; }
-constexpr int m_yt(int nw) { return (m_th(nw) + 8) * M_LW; }
+constexpr int M_YT = (M_TH + 8) * M_LW;            // one Y tile with its 4-sample halo
+constexpr int M_BPC = 2;                           // resident workgroups per CU
 constexpr int m_ybufs(bool ld) { return ld ? 2 : 1; }          // LDS-DMA staging double-buffers the Y tile
-constexpr int m_lds_floats(int nw, bool ld) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(ld) * m_yt(nw) + nw * M_C1 + 2; }   // + the two tile-queue slots
+constexpr int m_lds_floats(bool ld) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(ld) * M_YT + M_NW * M_C1 + 2; }   // + the two tile-queue slots
 
-// One tap-step of the product/accumulate pipeline.  PIPE=1: the MFMA of step t+1 is issued, then the VALU
-// folds in the result of step t (two result buffers).  PIPE=0: one buffer, the adds wait for their own
-// MFMA and other waves fill the gap (fewer registers -> more waves per SIMD).
-// LD: weights and Y tiles staged by LDS-DMA (the production form, variant 1); variant 4 is the same geometry with the
-// load -> wait -> ds_write staging it replaced (SRCNN_CONV12_VARIANT=4: A/B runs, and a fallback should the DMA path ever be suspected).
+// One tap-step = one MFMA (products) whose result the wave's own adds then wait for; the other three waves of the SIMD fill
+// the gap (one result buffer: 126 VGPRs -> 4 waves per SIMD.  The software-pipelined two-buffer forms and the 256-thread
+// geometries of rounds 1-4 measured 2-5 % slower and are gone: docs/HISTORY.md 4.1).
+// LD: weights and Y tiles staged by LDS-DMA one tile ahead (production); LD = false is the same geometry with the
+// load -> wait -> ds_write staging it replaced (SRCNN_CONV12_DMA=0: the fallback should the DMA path ever be suspected).
 // RELAX: bit 0 = layer 1, bit 1 = layer 2 evaluated as FMA chains on the matrix pipe (C = acc: one rounding per tap instead of
 // the reference's two).  0 = STRICT (production, bit-exact), 3 = SRCNN_MODE_FAST; 1 and 2 exist for the per-layer error
 // matrix (profiles/r04_error_matrix.txt) and the SRCNN_MODE_RELAXED experiments.
-template <int RELAX, int NW, int PIPE, int WPS, bool LD = false>
-__global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
+template <int RELAX, bool LD>
+__global__ __launch_bounds__(64 * M_NW, 4) void k_conv12_mfma(
     const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,
     float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles,
     unsigned long long* __restrict__ clk, unsigned* __restrict__ queue)
 {
-    constexpr int NT = 64 * NW, TH = m_th(NW), YT = m_yt(NW);
+    constexpr int NW = M_NW, NT = 64 * NW, TH = M_TH, YT = M_YT;
     // clk != NULL (srcnn_debug_clock_probe): workgroup 0 -- resident from the first round to the last -- stamps the shader
     // clock counter and the constant 100 MHz counter when it starts and when it ends: their ratio is the clock this launch ran at
     unsigned long long clk_c0 = 0, clk_r0 = 0;
@@ -962,28 +770,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
                     const float b = yrow[(t / 9) * M_LW + (t % 9)];
                     acc = __builtin_amdgcn_mfma_f32_32x32x1f32(a, b, acc, 0, 0, 0);
                 }
-            } else if constexpr (PIPE) {
-                float a1 = W1s[lane], b1 = yrow[0];
-                float a2 = W1s[64 + lane], b2 = yrow[1];
-                f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
-                a1 = a2; b1 = b2;
-                a2 = W1s[2 * 64 + lane]; b2 = yrow[2];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 81; ++t) {
-                    f32x32 d_next = zero32;
-                    if (t + 1 < 81) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
-                    __builtin_amdgcn_sched_barrier(0);
-                    a1 = a2; b1 = b2;
-                    if (t + 3 < 81) {
-                        a2 = W1s[(t + 3) * 64 + lane];
-                        b2 = yrow[((t + 3) / 9) * M_LW + ((t + 3) % 9)];
-                    }
-                    acc += d_cur;
-                    PIN(acc);
-                    d_cur = d_next;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             } else {
                 float a1 = W1s[lane], b1 = yrow[0];
                 float a2 = W1s[64 + lane], b2 = yrow[1];
@@ -1030,24 +816,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
 #pragma unroll
                     for (int fp = 0; fp < 16; ++fp)
                         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2p[fp * 64 + lane], myC1[fp * 64 + lane], acc2, 0, 0, 0);
-                } else if constexpr (PIPE) {
-                    f32x32 d_cur = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0);
-                    a1 = a2; b1 = b2;
-                    a2 = w2p[2 * 64 + lane]; b2 = myC1[2 * 64 + lane];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int fp = 0; fp < 16; ++fp) {
-                        f32x32 d_next = zero32;
-                        if (fp + 1 < 16) { d_next = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b1, zero32, 0, 0, 0); PIN(d_next); }
-                        __builtin_amdgcn_sched_barrier(0);
-                        a1 = a2; b1 = b2;
-                        if (fp + 3 < 16) { a2 = w2p[(fp + 3) * 64 + lane]; b2 = myC1[(fp + 3) * 64 + lane]; }
-                        acc2 += __builtin_shufflevector(d_cur, d_cur, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-                        acc2 += __builtin_shufflevector(d_cur, d_cur, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
-                        PIN(acc2);
-                        d_cur = d_next;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 } else {
 #pragma unroll
                     for (int fp = 0; fp < 16; ++fp) {
@@ -1089,206 +857,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_conv12_mfma(
         if (threadIdx.x == 0) {
             clk[0] = __builtin_amdgcn_s_memtime() - clk_c0;
             clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-        }
-    }
-}
-
-// =============================================================================================
-// FAST tier, layers 1+2 on the fp16 matrix pipe.  Never used in strict mode.
-//
-// Each fp32 operand is split into two fp16 pieces (x = hi + lo exactly to 22 bits; weights are pre-scaled
-// by 2^8 so their low pieces stay out of the fp16 subnormal range) and every product is evaluated as
-// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate, fp32 accumulation), i.e. three
-// MFMAs per 16-deep k-step.  Error vs exact arithmetic is ~1e-6 relative -- the same class as an fp32 FMA
-// evaluation, and like it ~2e-4 away from the reference's own rounding noise.
-//   layer 1 as GEMM  D[ch][px] = sum_k A[ch][k] B[k][px]:  A = weights (rows = 64 channels = 2 blocks),
-//     B = im2col(Y).  A k-step is one row of the 9x9 window: k 0..7 = taps dx 0..7, k 8..15 = taps dx 1..8 with
-//     only dx 8 carrying a weight, so each lane's B fragment is 8 CONTIGUOUS pixels of one tile row.  The
-//     fragment must be 8-byte aligned for ds_read_b64, so the fp16 tile is kept in 4 copies shifted by 0..3
-//     elements; a lane always reads from copy (x + h) & 3.
-//   layer 2: the layer-1 accumulator tile X (rows = channels, column = this lane's pixel) IS the B operand of
-//     the next MFMA (it sums over X's row index): registers 8s..8s+7 converted to fp16 form k-step s with the
-//     permuted k order row = 16s + 8(j>>2) + 4h + (j&3); the W2 fragments are laid out in that order.  No LDS.
-// =============================================================================================
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-constexpr int F_TW = 64, F_TH = 8, F_LH = F_TH + 8, F_RS = 80;          // tile, staged rows, row stride (halves)
-constexpr int F_CS = 2 * F_LH * F_RS + 16;                              // copy stride in halves: = 32 B mod 128 B, so the
-                                                                        // four copies that neighbouring lanes read
-                                                                        // fall on different banks
-constexpr int F_YC = 4 * F_CS;                                          // [copy]{[hi/lo][row][i]} halves
-constexpr int F_W1 = 9 * 2 * 2 * 64 * 8;                                // [dy][blk][hi/lo][lane][8] halves
-constexpr int F_W2 = 2 * 2 * 2 * 64 * 8;                                // [blk][kstep][hi/lo][lane][8] halves
-constexpr float F_SCALE = 256.f, F_INV = 1.f / 256.f;
-constexpr size_t F_LDS_BYTES = 2 * (size_t)(F_YC + F_W1 + F_W2) + 4 * (64 + 32);
-
-__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo)
-{
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
-}
-
-__global__ __launch_bounds__(256, 2) void k_conv12_f16(
-    const float* __restrict__ Y, int W, int H, int y_row_base, int y_rows,
-    float* __restrict__ C2, size_t plane_stride, int out_row0, int out_rows, int tiles_x, int ntiles)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    _Float16* Yc = reinterpret_cast<_Float16*>(lds_raw);
-    _Float16* W1f = Yc + F_YC;
-    _Float16* W2f = W1f + F_W1;
-    float* B1s = reinterpret_cast<float*>(W2f + F_W2);
-    float* B2s = B1s + 64;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
-
-    // ---- weight fragments (once per block) ----
-    for (int e = tid; e < 9 * 2 * 64 * 8; e += 256) {
-        const int j = e & 7, l = (e >> 3) & 63, blk = (e >> 9) & 1, s = e >> 10;
-        const int ch = 32 * blk + (l & 31), h = l >> 5;
-        float w = 0.f;
-        if (h == 0) w = cW.w1t[s * 9 + j][ch];
-        else if (j == 7) w = cW.w1t[s * 9 + 8][ch];
-        _Float16 hi, lo;
-        split_f16(w * F_SCALE, hi, lo);
-        W1f[(((s * 2 + blk) * 2 + 0) * 64 + l) * 8 + j] = hi;
-        W1f[(((s * 2 + blk) * 2 + 1) * 64 + l) * 8 + j] = lo;
-    }
-    for (int e = tid; e < 2 * 2 * 64 * 8; e += 256) {
-        const int j = e & 7, l = (e >> 3) & 63, ks = (e >> 9) & 1, blk = e >> 10;
-        const int m = l & 31, h = l >> 5;
-        const int f = 32 * blk + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
-        _Float16 hi, lo;
-        split_f16(cW.w2[m][f] * F_SCALE, hi, lo);
-        W2f[(((blk * 2 + ks) * 2 + 0) * 64 + l) * 8 + j] = hi;
-        W2f[(((blk * 2 + ks) * 2 + 1) * 64 + l) * 8 + j] = lo;
-    }
-    if (tid < 64) {
-        const int hf = tid >> 5, r = tid & 31;
-        B1s[tid] = cW.b1[32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * hf + (r & 3)];
-    }
-    if (tid < 32) {
-        const int hf = tid >> 4, r = tid & 15;
-        B2s[tid] = cW.b2[8 * (r >> 2) + 4 * hf + (r & 3)];
-    }
-
-    // The Y values of the NEXT tile are fetched into registers while the current tile is being computed.
-    constexpr int F_PRE = (F_LH * (F_TW + 8) + 255) / 256;
-    float pre[F_PRE];
-    auto fetch = [&](int tile) {
-        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int tx0 = txi * F_TW, ty0 = out_row0 + tyi * F_TH;
-#pragma unroll
-        for (int k = 0; k < F_PRE; ++k) {
-            const int e = tid + 256 * k;
-            const int r = e / (F_TW + 8), c0 = e - r * (F_TW + 8);
-            const int gy = clampi(clampi(ty0 + r - 4, 0, H - 1), y_row_base, y_row_base + y_rows - 1), gx = clampi(tx0 + c0 - 4, 0, W - 1);
-            pre[k] = (e < F_LH * (F_TW + 8)) ? Y[(size_t)(gy - y_row_base) * W + gx] : 0.f;
-        }
-    };
-    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
-
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int tx0 = txi * F_TW, ty0 = out_row0 + tyi * F_TH;
-        __syncthreads();
-        // ---- fp16 hi/lo tile, 4 shifted copies: copy c, index i holds tile column i + c ----
-#pragma unroll
-        for (int k = 0; k < F_PRE; ++k) {
-            const int e = tid + 256 * k;
-            if (e < F_LH * (F_TW + 8)) {
-                const int r = e / (F_TW + 8), c0 = e - r * (F_TW + 8);
-                _Float16 hi, lo;
-                split_f16(pre[k], hi, lo);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int i = c0 - c;
-                    if (i >= 0) {
-                        Yc[c * F_CS + (0 * F_LH + r) * F_RS + i] = hi;
-                        Yc[c * F_CS + (1 * F_LH + r) * F_RS + i] = lo;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-
-#pragma unroll 1
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const int sg = wv * 4 + sidx;
-            const int trow = sg >> 1, seg = sg & 1;
-            const int q = seg * 32 + col + half, cpy = q & 3, bi = q - cpy;
-            const _Float16* yh = Yc + cpy * F_CS + (0 * F_LH + trow) * F_RS + bi;
-            const _Float16* yl = Yc + cpy * F_CS + (1 * F_LH + trow) * F_RS + bi;
-
-            f32x16 acc0 = {}, acc1 = {};
-            // k-step fragments are fetched one step ahead of the MFMAs that consume them
-            auto ld_b = [&](int s, h8& bh, h8& bl) {
-                // two 8-byte reads per fragment, kept apart by a compiler barrier: merged into one ds_read_b128
-                // they would be misaligned for half of the lanes and replay
-                const h4 bh0 = *reinterpret_cast<const h4*>(yh + s * F_RS), bl0 = *reinterpret_cast<const h4*>(yl + s * F_RS);
-                asm volatile("" ::: "memory");
-                const h4 bh1 = *reinterpret_cast<const h4*>(yh + s * F_RS + 4), bl1 = *reinterpret_cast<const h4*>(yl + s * F_RS + 4);
-                bh = __builtin_shufflevector(bh0, bh1, 0, 1, 2, 3, 4, 5, 6, 7);
-                bl = __builtin_shufflevector(bl0, bl1, 0, 1, 2, 3, 4, 5, 6, 7);
-            };
-            auto ld_a = [&](int s, int blk, int hl) {
-                return *reinterpret_cast<const h8*>(W1f + (((s * 2 + blk) * 2 + hl) * 64 + lane) * 8);
-            };
-            h8 bh, bl, a0h, a0l, a1h, a1l;
-            ld_b(0, bh, bl);
-            a0h = ld_a(0, 0, 0); a0l = ld_a(0, 0, 1); a1h = ld_a(0, 1, 0); a1l = ld_a(0, 1, 1);
-#pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                h8 nbh = bh, nbl = bl, n0h = a0h, n0l = a0l, n1h = a1h, n1l = a1l;
-                if (s + 1 < 9) {
-                    ld_b(s + 1, nbh, nbl);
-                    n0h = ld_a(s + 1, 0, 0); n0l = ld_a(s + 1, 0, 1); n1h = ld_a(s + 1, 1, 0); n1l = ld_a(s + 1, 1, 1);
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh, acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                bh = nbh; bl = nbl; a0h = n0h; a0l = n0l; a1h = n1h; a1l = n1l;
-            }
-            // ---- bias + ReLU (undo the weight scale first: exact power of two) ----
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc0[r] = fmaxf(acc0[r] * F_INV + B1s[half * 32 + r], 0.f);
-                acc1[r] = fmaxf(acc1[r] * F_INV + B1s[half * 32 + 16 + r], 0.f);
-            }
-            // ---- layer 2: the accumulator tiles are the B operands ----
-            f32x16 acc2 = {};
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    h8 xh, xl;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = blk ? acc1[8 * ks + j] : acc0[8 * ks + j];
-                        _Float16 hi, lo;
-                        split_f16(x, hi, lo);
-                        xh[j] = hi; xl[j] = lo;
-                    }
-                    const h8 ah = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 0) * 64 + lane) * 8);
-                    const h8 al = *reinterpret_cast<const h8*>(W2f + (((blk * 2 + ks) * 2 + 1) * 64 + lane) * 8);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc2, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc2, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc2, 0, 0, 0);
-                }
-            const int row = ty0 + trow, x = tx0 + seg * 32 + col;
-            if (row < out_row0 + out_rows && row < H && x < W) {
-                float* dst = C2 + (size_t)(row - out_row0) * W + x;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = 8 * (r >> 2) + (r & 3);
-                    dst[(size_t)(m + 4 * half) * plane_stride] = fmaxf(acc2[r] * F_INV + B2s[half * 16 + r], 0.f);
-                }
-            }
         }
     }
 }
@@ -1697,28 +1265,9 @@ void launch_resample_rows(const float* src, int src_w, float* dst, int dst_w, in
                           hipStream_t s)
 {
     if (rows <= 0) return;
-    if (t.max_taps <= RS_MAXT) {
-        dim3 grid(cdiv(dst_w, 256), std::min<unsigned>(cdiv(rows, RS_RPT), 65535u));
-        hipLaunchKernelGGL(k_resample_rows_reg, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
-                           t.weight, t.stride);
-        return;
-    }
     dim3 grid(cdiv(dst_w, 256), std::min(rows, 65535));
     hipLaunchKernelGGL(k_resample_rows, grid, dim3(256), 0, s, src, src_w, dst, dst_w, rows, t.first, t.taps,
                        t.weight, t.stride);
-}
-
-bool launch_resample_2d(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, int dst_row0, int dst_rows,
-                        const DevAxisTable& tv, const DevAxisTable& th, hipStream_t s)
-{
-    // only where a tile's taps span at most R2_LW source columns and R2_SR source rows: up-scales in both axes with short tables
-    if (dst_rows <= 0 || dst_w < src_w || dst_h < src_h || th.max_taps > RS_MAXT || tv.max_taps > RS_MAXT || th.max_taps + R2_TW > R2_LW)
-        return false;
-    dim3 grid(cdiv(dst_w, R2_TW), std::min<unsigned>(cdiv(dst_rows, R2_TH), 65535u * 16u));
-    if (grid.y > 65535u) return false;
-    hipLaunchKernelGGL(k_resample_2d, grid, dim3(R2_TW), 0, s, src, src_w, dst, dst_w, dst_row0, dst_rows, tv.first, tv.taps,
-                       tv.weight, tv.stride, th.first, th.taps, th.weight, th.stride);
-    return true;
 }
 
 // ---- k_rs2d launchers ----
@@ -1753,7 +1302,7 @@ Rs2dPlan rs2d_plan(int np, int dst_w, int dst_row0, int dst_rows, const DevAxisT
     // a block marches through `tpb` row tiles with its horizontal weights in registers; keep >= ~4 blocks per CU in the grid
     const unsigned tiles_y = cdiv(dst_rows, RS_TH);
     p.gx = cdiv(dst_w, 256);
-    static const int tpb_env = [] { const char* e = getenv("SRCNN_RS_TPB"); return e ? atoi(e) : 0; }();
+    const int tpb_env = (int)settings().rs_tpb;
     // one round of resident blocks where possible (4 blocks per CU x 256 CUs: a grid of 1.1 rounds runs as long as one of 2:
     // measured 0.088 ms at tpb 7 = 1170 blocks vs 0.075 ms at tpb 8 = 1020 blocks for an 8K plane)
     p.tpb = tpb_env > 0 ? std::min(tpb_env, RS_MAX_TPB) : (int)std::max(1u, std::min<unsigned>(RS_MAX_TPB, cdiv(p.gx * tiles_y, 1024u)));
@@ -1821,7 +1370,7 @@ bool launch_rs2d(const YSource& src, int src_w, int src_h, float* dst, int dst_w
     a.vfirst = tv.first; a.vtaps = tv.taps; a.vwt = tv.weight; a.vstride = tv.stride;
     a.hfirst = th.first; a.htaps = th.taps; a.hwt = th.weight; a.hstride = th.stride;
     a.vec = (dst_w % 4 == 0) && aligned_to(dst, 16);
-    static const bool dma = [] { const char* e = getenv("SRCNN_RS_DMA"); return !(e && e[0] == '0'); }();
+    const bool dma = settings().rs_dma;
     const size_t lds_dma = p.lds + (size_t)RS_TH * p.lw * 4;  // its intermediate rows are doubles
     if (src.plane && dma && lds_dma <= (size_t)64 * 1024) {    // (M0 carries the DMA's LDS address: stay inside what a 16-bit field reaches)
         const dim3 grid(p.gx, p.gy), block(256);
@@ -1856,113 +1405,53 @@ bool launch_merge_fused(const unsigned char* rgb_src, int src_w, int src_h, int 
     return true;
 }
 
-void launch_conv12(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                   int out_rows, bool strict, hipStream_t s)
-{
-    if (out_rows <= 0) return;
-    constexpr int PX = 2;
-    dim3 grid(cdiv(W, 64 * PX), cdiv(out_rows, 4));
-    if (strict)
-        hipLaunchKernelGGL((k_conv12<PX, true>), grid, dim3(256), 0, s, Y, W, H, y_row_base, y_rows, C2, plane_stride,
-                           out_row0, out_rows);
-    else
-        hipLaunchKernelGGL((k_conv12<PX, false>), grid, dim3(256), 0, s, Y, W, H, y_row_base, y_rows, C2, plane_stride,
-                           out_row0, out_rows);
-}
-
-// Variants of the layer-1+2 kernel (selected by SRCNN_CONV12_VARIANT for A/B runs; 1 is the default, fastest
-// by 2-5 % on MI355X):
-//   0: 256 threads, pipelined (two result buffers), 3 waves/SIMD      1: 512 threads, single buffer, 4 waves/SIMD
-//   2: 256 threads, single buffer, 3 waves/SIMD                        3: 512 threads, pipelined, 2 waves/SIMD
-template <int RELAX, int NW, int PIPE, int WPS, bool LD>
+// The layer-1+2 kernel's instantiations: RELAX 0 = strict (production, and its no-DMA fallback), 3 = SRCNN_MODE_FAST, 1 / 2 = the
+// single-layer relaxations of SRCNN_MODE_RELAXED (the instrument behind profiles/r04_error_matrix.txt).
+template <int RELAX, bool LD>
 static hipError_t prep_one()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<RELAX, NW, PIPE, WPS, LD>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * m_lds_floats(NW, LD)));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_mfma<RELAX, LD>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * m_lds_floats(LD)));
 }
 
 hipError_t conv12_mfma_prepare()
 {
     hipError_t e;
-#define PREP(NW, PIPE, WPS, LD)                                        \
-    if ((e = prep_one<0, NW, PIPE, WPS, LD>()) != hipSuccess) return e; \
-    if ((e = prep_one<3, NW, PIPE, WPS, LD>()) != hipSuccess) return e;
-    PREP(4, 1, 3, false) PREP(8, 0, 4, true) PREP(4, 0, 3, false) PREP(8, 1, 2, false) PREP(8, 0, 4, false)
-#undef PREP
-    // the single-layer relaxations exist for the production geometry only
-    if ((e = prep_one<1, 8, 0, 4, true>()) != hipSuccess) return e;
-    if ((e = prep_one<2, 8, 0, 4, true>()) != hipSuccess) return e;
+    if ((e = prep_one<0, true>()) != hipSuccess) return e;
+    if ((e = prep_one<0, false>()) != hipSuccess) return e;
+    if ((e = prep_one<1, true>()) != hipSuccess) return e;
+    if ((e = prep_one<2, true>()) != hipSuccess) return e;
+    if ((e = prep_one<3, true>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
-hipError_t conv12_f16_prepare()
+// Resident workgroups of the layer-1+2 kernel (it loops over 64 x 16 tiles) and its tile height: what a band planner needs
+// to cut bands whose tile count fills whole rounds of the grid.
+void conv12_grid_info(int num_cus, int* blocks, int* tile_rows)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_f16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)F_LDS_BYTES);
-}
-
-void launch_conv12_f16(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                       int out_rows, int num_cus, hipStream_t s)
-{
-    if (out_rows <= 0) return;
-    const int tiles_x = (int)cdiv(W, F_TW), tiles_y = (int)cdiv(out_rows, F_TH);
-    const int ntiles = tiles_x * tiles_y;
-    const int grid = std::min(ntiles, 2 * num_cus);
-    hipLaunchKernelGGL(k_conv12_f16, dim3(grid), dim3(256), F_LDS_BYTES, s, Y, W, H, y_row_base, y_rows, C2, plane_stride,
-                       out_row0, out_rows, tiles_x, ntiles);
-}
-
-template <int NW, int PIPE, int WPS, bool LD>
-static void launch_v(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                     int out_rows, int relax, int num_cus, int blocks_per_cu, hipStream_t s, unsigned long long* clk, unsigned* queue)
-{
-    const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, m_th(NW));
-    const int ntiles = tiles_x * tiles_y;
-    // resident blocks only; tile loop inside.  Fewer tiles than resident blocks (small images, short bands): the kernel deals
-    // such a "last round" out in quarter tiles, so up to four blocks share a tile instead of three quarters of the chip idling
-    const int cap = blocks_per_cu * num_cus;
-    static const bool spread = [] { const char* e = getenv("SRCNN_CONV12_SPREAD"); return !(e && e[0] == '0'); }();   // A/B
-    const int grid = ntiles >= cap ? cap : (spread ? std::min(4 * ntiles, cap) : ntiles);
-    const size_t lds = sizeof(float) * m_lds_floats(NW, LD);
-#define CONV12_GO(R) hipLaunchKernelGGL((k_conv12_mfma<R, NW, PIPE, WPS, LD>), dim3(grid), dim3(64 * NW), lds, s, Y, W, H, y_row_base, \
-                                       y_rows, C2, plane_stride, out_row0, out_rows, tiles_x, ntiles, clk, LD ? queue : nullptr)
-    relax &= 3;
-    if (relax == 0) CONV12_GO(0);
-    else if (relax == 3) CONV12_GO(3);
-    else if constexpr (NW == 8 && PIPE == 0 && WPS == 4 && LD) { if (relax == 1) CONV12_GO(1); else CONV12_GO(2); }
-    else CONV12_GO(3);            // (the A/B geometries have no single-layer forms; the C-ABI layer never asks them for one)
-#undef CONV12_GO
-}
-
-// Resident workgroups of the production layer-1+2 kernel (it loops over 64 x TH tiles with a static stride) and its tile
-// height: what a band planner needs to cut bands whose tile count fills whole rounds of the grid.
-void conv12_grid_info(int num_cus, int variant, int* blocks, int* tile_rows)
-{
-    int bpc = 2, th = m_th(8);
-    switch (variant) {
-    case 0: bpc = 3; th = m_th(4); break;
-    case 2: bpc = 3; th = m_th(4); break;
-    case 3: bpc = 1; th = m_th(8); break;
-    default: break;
-    }
-    if (blocks) *blocks = bpc * num_cus;
-    if (tile_rows) *tile_rows = th;
+    if (blocks) *blocks = M_BPC * num_cus;
+    if (tile_rows) *tile_rows = M_TH;
 }
 
 void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows, float* C2, size_t plane_stride, int out_row0,
-                        int out_rows, int relax, int num_cus, int variant, hipStream_t s, unsigned long long* clk, unsigned* queue)
+                        int out_rows, int relax, int num_cus, hipStream_t s, unsigned long long* clk, unsigned* queue)
 {
     if (out_rows <= 0) return;
-    static const bool dyn = [] { const char* e = getenv("SRCNN_CONV12_QUEUE"); return !(e && e[0] == '0'); }();     // A/B: 0 = static stride
-    if (!dyn) queue = nullptr;
-    if ((relax & 3) == 1 || (relax & 3) == 2) variant = 1;
-    switch (variant) {
-    case 0: launch_v<4, 1, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 3, s, clk, queue); break;
-    default: launch_v<8, 0, 4, true>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 2, s, clk, queue); break;
-    case 2: launch_v<4, 0, 3, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 3, s, clk, queue); break;
-    case 3: launch_v<8, 1, 2, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 1, s, clk, queue); break;
-    case 4: launch_v<8, 0, 4, false>(Y, W, H, y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, relax, num_cus, 2, s, clk, queue); break;
+    const int tiles_x = (int)cdiv(W, M_TW), tiles_y = (int)cdiv(out_rows, M_TH);
+    const int ntiles = tiles_x * tiles_y;
+    // resident blocks only; tile loop inside.  Fewer tiles than resident blocks (small images, short bands): the kernel deals
+    // such a "last round" out in quarter tiles, so up to four blocks share a tile instead of three quarters of the chip idling
+    const int cap = M_BPC * num_cus;
+    const int grid = ntiles >= cap ? cap : (settings().conv12_spread ? std::min(4 * ntiles, cap) : ntiles);
+#define CONV12_GO(R, LD) hipLaunchKernelGGL((k_conv12_mfma<R, LD>), dim3(grid), dim3(64 * M_NW), sizeof(float) * m_lds_floats(LD), s, Y, W, H, \
+                                           y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, tiles_x, ntiles, clk, LD ? queue : nullptr)
+    switch (relax & 3) {
+    case 0: if (settings().conv12_dma) CONV12_GO(0, true); else CONV12_GO(0, false); break;
+    case 1: CONV12_GO(1, true); break;
+    case 2: CONV12_GO(2, true); break;
+    default: CONV12_GO(3, true); break;
     }
+#undef CONV12_GO
 }
 
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
@@ -1986,17 +1475,14 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
         return;
     }
     dim3 grid(cdiv(W, 64), cdiv(out_rows, 16));
-    static const bool force_wide = [] { const char* e = getenv("SRCNN_CONV3_OFF64"); return e && e[0] == '1'; }();    // test hook
-    static const int wdma = [] { const char* e = getenv("SRCNN_CONV3_WDMA"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool force_wide = settings().conv3_off64;      // test hook
+    const int wdma = settings().conv3_wdma ? 1 : 0;
     const bool wide = force_wide || (size_t)c2_rows * (size_t)W * sizeof(float) >= ((size_t)1 << 32);     // per-plane byte offsets beyond 32 bits
-    if (strict && !wide)
+    if (!wide)
         hipLaunchKernelGGL((k_conv3<true, false>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
                            out, out_row0, out_rows, wdma);
-    else if (strict)
-        hipLaunchKernelGGL((k_conv3<true, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
-                           out, out_row0, out_rows, wdma);
     else
-        hipLaunchKernelGGL((k_conv3<false, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
+        hipLaunchKernelGGL((k_conv3<true, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
                            out, out_row0, out_rows, wdma);
 }
 

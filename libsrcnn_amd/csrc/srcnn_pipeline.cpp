@@ -46,8 +46,7 @@ bool is_pinned(const void* p)
 // huge pages it runs at memory speed (1.5 ms) -- profiles/r03_host_out_probe.txt.  A hint only: harmless where THP is off.
 void hint_huge_pages(void* p, size_t n)
 {
-    static const bool off = [] { const char* e = getenv("SRCNN_THP"); return e && atoi(e) == 0; }();   // A/B runs: a host with THP = never
-    if (off) return;
+    if (!settings().thp) return;                               // A/B runs: a host with THP = never
     const uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 4095) & ~uintptr_t(4095);
     const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + n) & ~uintptr_t(4095);
     if (e > a + (4u << 20)) (void)madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);
@@ -286,7 +285,7 @@ std::vector<unsigned> band_starts(unsigned R0, unsigned R1, unsigned dw, unsigne
     // SRCNN_BANDS="f0,f1,...": band fractions of a lone share for A/B runs (the last band is what is left)
     static const std::vector<double> env_plan = [] {
         std::vector<double> v;
-        if (const char* e = getenv("SRCNN_BANDS")) {
+        if (const char* e = settings().bands.empty() ? nullptr : settings().bands.c_str()) {
             double sum = 0;
             for (const char* q = e; *q;) {
                 char* end = nullptr;
@@ -360,7 +359,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     // up-scale in both axes with short monotone tables -- anything else takes the plane path below.
     // (the fused shell feeds the Y path an RGB source, which only k_rs2d can read: the switches that force the older plane
     //  resamplers therefore select the plane shell as well)
-    bool fused_shell = !G.shell_unfused && !G.resample_two_pass && !G.resample_old2d && !identity && dw > w && dh > h;
+    bool fused_shell = !settings().shell_unfused && !settings().resample_2pass && !identity && dw > w && dh > h;
     if (fused_shell) {
         if ((rc = get_table(c, J.cfilter, dw, w, ch_))) return rc;
         if ((rc = get_table(c, J.filter, dh, h, yv))) return rc;
@@ -392,12 +391,12 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 
     // ---- bands ----
     int grid = 0, tile_rows = 0;
-    if ((J.mode & 0xff) != SRCNN_MODE_FAST_F16 && !G.conv12_valu) conv12_grid_info(cx.num_cus, G.conv12_variant, &grid, &tile_rows);
+    if ((J.mode & 0xff) != SRCNN_MODE_FAST_F16) conv12_grid_info(cx.num_cus, &grid, &tile_rows);
     const std::vector<unsigned> cuts = band_starts(R0, R1, dw, dh, one_of_many, grid, tile_rows);
     const unsigned nb = (unsigned)cuts.size() - 1;
     unsigned max_band = 0;
     for (unsigned b = 0; b < nb; ++b) max_band = std::max(max_band, cuts[b + 1] - cuts[b]);
-    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16 && !G.f16_unfused;           // the fused kernel has no layer-2 planes
+    const bool no_planes = c.mode == SRCNN_MODE_FAST_F16;           // the fused kernel has no layer-2 planes
     if (!no_planes && (rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * std::min(dh, max_band + 4)))) return rc;
     if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * std::min(dh, max_band + 12)))) return rc;
     if (!fused_shell && (rc = grow_ws(ws, ws.tmp, ws.tmp_n, (size_t)std::max(w, dw) * std::max(h, std::min(dh, max_band + 12))))) return rc;
@@ -443,8 +442,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
             hipEvent_t ev = L.band_events[2 * nb + n_staged++];
             HIP_TRY(hipMemcpyAsync(d_rgb + off, from, nbytes, hipMemcpyHostToDevice, L.in_st));
             HIP_TRY(hipEventRecord(ev, L.in_st));
-            static const bool device_wait = [] { const char* e = getenv("SRCNN_DEVICE_WAIT_IN"); return e && atoi(e) != 0; }();
-            if (device_wait) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+            if (settings().device_wait_in) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
             else if (wait_event(ev) != hipSuccess) return fail(SRCNN_E_HIP, "stage-in copy");
         }
         if (!fused_shell)
@@ -475,9 +473,8 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
             hint_huge_pages(o0, out_bytes);
             if (c0) hint_huge_pages(c0, share_px);
         }
-        static const bool no_prefault = [] { const char* e = getenv("SRCNN_PREFAULT"); return e && atoi(e) == 0; }();
-        static const int pf_threads = [] { const char* e = getenv("SRCNN_PREFAULT_THREADS"); return e ? std::max(1, atoi(e)) : 1; }();
-        if (!no_prefault && !out_pinned) prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes, pf_threads); if (c0) prefault_pages(c0, share_px); });
+        const int pf_threads = (int)settings().prefault_threads;
+        if (settings().prefault && !out_pinned) prefaulting = try_thread(prefault, [=] { prefault_pages(o0, out_bytes, pf_threads); if (c0) prefault_pages(c0, share_px); });
     }
     struct JoinPrefault {                                      // whatever path leaves this function: the helper is joined first
         std::thread& t; bool& on;
@@ -500,8 +497,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
             // resolved on the HOST by default (this thread polls the predecessor's last-kernel event, then queues): a device-side
             // hipStreamWaitEvent across streams is resolved by a thread of the runtime on this ROCm and measured slower
             // (SRCNN_ASYNC_CHAIN=2 selects it for A/B runs)
-            static const bool device_side = [] { const char* e = getenv("SRCNN_ASYNC_CHAIN"); return e && e[0] == '2'; }();
-            if (device_side) HIP_TRY(hipStreamWaitEvent(s, a.ev, 0));
+            if (settings().async_chain == 2) HIP_TRY(hipStreamWaitEvent(s, a.ev, 0));
             else if (wait_event(a.ev) != hipSuccess) return fail(SRCNN_E_HIP, "waiting for the previous asynchronous job's kernels");
         }
         return SRCNN_OK;
@@ -655,7 +651,7 @@ int srcnn_debug_band_plan(unsigned r0, unsigned r1, unsigned dw, int one_of_many
 {
     if (r1 <= r0 || dw == 0) return fail(SRCNN_E_ARG, "empty row range");
     int grid = 0, tile_rows = 0;
-    conv12_grid_info(256, G.conv12_variant, &grid, &tile_rows);          // an MI355X: 256 CUs
+    conv12_grid_info(256, &grid, &tile_rows);          // an MI355X: 256 CUs
     const std::vector<unsigned> c = band_starts(r0, r1, dw, r1, one_of_many != 0, grid, tile_rows);
     for (int i = 0; i < (int)c.size() && i < cap; ++i) cuts[i] = c[i];
     return (int)c.size();
@@ -739,18 +735,18 @@ int srcnn_y_upscale2x_f32_batch(const float* in, unsigned w, unsigned h, unsigne
 
 namespace {
 int process_u8_impl(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
-                    unsigned char* out, unsigned char* conv_opt, AsyncLink* after, AsyncLink* mine);
+                    unsigned char* out, unsigned char* conv_opt, int mode, AsyncLink* after, AsyncLink* mine);
 }
 
 int srcnn_process_u8(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
                      unsigned char* out, unsigned char* conv_opt)
 {
-    return process_u8_impl(rgb, w, h, d, multiply, filter, out, conv_opt, nullptr, nullptr);
+    return process_u8_impl(rgb, w, h, d, multiply, filter, out, conv_opt, G.mode.load(), nullptr, nullptr);
 }
 
 namespace {
 int process_u8_impl(const unsigned char* rgb, unsigned w, unsigned h, unsigned d, float multiply, int filter,
-                    unsigned char* out, unsigned char* conv_opt, AsyncLink* after, AsyncLink* mine)
+                    unsigned char* out, unsigned char* conv_opt, int mode, AsyncLink* after, AsyncLink* mine)
 {
     if (!rgb || !out || w == 0 || h == 0 || d == 0) return fail(SRCNN_E_ARG, "NULL pointer or zero dimension");
     if (d != 3 && d != 4) return fail(SRCNN_E_UNSUPPORTED, "depth %u: the reference reads uninitialised planes for d<3 (src/libsrcnn.cpp:235-236)", d);
@@ -765,8 +761,8 @@ int process_u8_impl(const unsigned char* rgb, unsigned w, unsigned h, unsigned d
     ProcJob J;
     J.rgb = rgb; J.w = w; J.h = h; J.d = d; J.dw = dw; J.dh = dh; J.filter = filter;
     J.cfilter = (filter == SRCNN_FILTER_NEAREST) ? SRCNN_FILTER_NEAREST : SRCNN_FILTER_BILINEAR;   // src/libsrcnn.cpp:701-713
-    J.mode = G.mode.load(); J.out = out; J.conv = conv_opt;
-    J.trace = getenv("SRCNN_TRACE") != nullptr;
+    J.mode = mode; J.out = out; J.conv = conv_opt;
+    J.trace = settings().trace;
 
     // Everything runs on lanes leased for this call only (see ProcLane): concurrent ProcessSRCNN calls from several host
     // threads are independent, like the reference's.  A large image is dealt over all contexts of the process in
@@ -853,8 +849,10 @@ int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, uns
     const int ctx_index = cur->index;
     AsyncJob* a = new (std::nothrow) AsyncJob;
     if (!a) return fail(SRCNN_E_OUTALLOC, "out of memory");
-    static const bool chain = [] { const char* e = getenv("SRCNN_ASYNC_CHAIN"); return !(e && e[0] == '0'); }();      // A/B runs
-    if (chain) {
+    // the numerics mode of the image is the one in force NOW, not whenever the worker thread gets going: srcnn_amd.h promises
+    // that srcnn_set_mode / srcnn_set_relaxation only affect calls that start later
+    const int mode = G.mode.load();
+    if (settings().async_chain != 0) {
         a->mine = std::make_shared<AsyncLink>();
         std::lock_guard<std::mutex> lk(g_async_mu);
         auto& tail = async_tails()[ctx_index];
@@ -863,7 +861,7 @@ int srcnn_process_u8_begin(const unsigned char* rgb, unsigned w, unsigned h, uns
     }
     auto work = [=] {
         (void)srcnn_set_context(ctx_index);                   // the worker inherits the caller's current context
-        a->rc = process_u8_impl(rgb, w, h, d, multiply, filter, out, conv_opt, a->after.get(), a->mine.get());
+        a->rc = process_u8_impl(rgb, w, h, d, multiply, filter, out, conv_opt, mode, a->after.get(), a->mine.get());
         if (a->rc) a->err = srcnn_last_error();
         if (a->mine) a->mine->settle(false);                  // a job that never recorded its link (error, dealt-out image) releases its successor
     };

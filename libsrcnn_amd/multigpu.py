@@ -140,7 +140,14 @@ class TiledFrameGPU:
         S.check(L.srcnn_comm_tiled_y_upscale2x_f32_dev(d_in.ptr, self.w, self.h, self.d_band.ptr,
                                                        self.d_full.ptr if self.d_full else None, self.root, self.nsub, stream))
 
-    def result(self):
-        """Host copy of the assembled frame (root only)."""
+    def wait(self, stream=None):
+        """Bounded host wait for the frame queued by step() on `stream` (srcnn_comm_wait: SRCNN_E_COMM instead of a hang when a
+        peer is missing), on every rank."""
+        self.S.check(self.S.lib().srcnn_comm_wait(stream))
+
+    def result(self, stream=None):
+        """Host copy of the assembled frame (root only).  Waits through srcnn_comm_wait first: a plain device sync would hang
+        for ever behind a receive whose peer died."""
+        self.wait(stream)
         self.S.sync()
         return self.d_full.to_numpy(np.float32, (2 * self.h, 2 * self.w))

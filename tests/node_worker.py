@@ -250,8 +250,8 @@ def cmd_env_devices(_):
 
 
 def cmd_process_paths(_):
-    """ProcessSRCNN through whatever kernel selection the environment asks for (SRCNN_SHELL_UNFUSED, SRCNN_RESAMPLE_OLD2D,
-    SRCNN_RESAMPLE_2PASS, SRCNN_RS_TH, SRCNN_MAX_WORKSPACE_MB ...): always the oracle's bytes."""
+    """ProcessSRCNN through whatever kernel selection the environment asks for (SRCNN_SHELL_UNFUSED, SRCNN_RESAMPLE_2PASS,
+    SRCNN_RS_TPB, SRCNN_MAX_WORKSPACE_MB ...): always the oracle's bytes."""
     S.init(0)
     orc = oracle.Oracle()
     ok = []

@@ -1,7 +1,7 @@
 """Worker for tests/test_gpu_stress.py and tools/dma_stress.sh: the launch pattern that once ended in a silent SIGABRT
 (DESIGN history, round 3: small-shape parity launches, each followed at once by the NEXT case's host-to-device copy) repeated
 thousands of times over random shapes 1..130, every result compared bit for bit with the oracle.  Runs in its OWN process so
-that the kernel selection comes from the environment (SRCNN_CONV12_VARIANT, SRCNN_CONV3_WDMA, SRCNN_CONV12_SPREAD ...) and
+that the kernel selection comes from the environment (SRCNN_CONV12_DMA, SRCNN_CONV3_WDMA, SRCNN_CONV12_SPREAD ...) and
 so that a runtime abort leaves its stderr in a file instead of in pytest's capture buffer.  Test infrastructure: uses oracle/.
 
     python tests/stress_worker.py ITERATIONS SEED [POOL [POOL_FILE]]      -> one JSON line; exit code 1 on any mismatch"""

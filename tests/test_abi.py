@@ -39,7 +39,39 @@ def test_reference_cxx_symbols_exported(S):
     L = S.lib()
     for sym in S.CXX_SYMBOLS:
         assert hasattr(L, sym), sym
-    assert L.srcnn_abi_version() == 4
+    assert L.srcnn_abi_version() == 5
+
+
+def test_exports_are_exactly_the_abi(S):
+    """nm -D --defined-only: the C ABI of include/srcnn_amd.h plus the two symbols of the reference's src/libsrcnn.h:46-54, and
+    nothing else (csrc/exports.map; the HIP kernels' launch stubs used to leak out although the TUs are -fvisibility=hidden)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", S.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert names == sorted(S.C_ABI_SYMBOLS + S.CXX_SYMBOLS), set(names) ^ set(S.C_ABI_SYMBOLS + S.CXX_SYMBOLS)
+
+
+def test_settings_are_one_table_and_design_md_carries_it(S):
+    """Every SRCNN_* switch lives in csrc/srcnn_settings.hpp, is read once, and is printable (srcnn_debug_settings, no device);
+    DESIGN.md section 6 is generated from the same table (tools/gen_settings_table.py) and must carry exactly its rows."""
+    import subprocess
+    import sys
+    text = S.debug_settings()
+    names = [ln.split("=")[0] for ln in text.splitlines()]
+    assert len(names) >= 20 and len(set(names)) == len(names) and all(n.startswith("SRCNN_") for n in names)
+    # no launcher keeps a private getenv: the only one in the product is the table reader
+    src = "".join(open(os.path.join(ROOT, "libsrcnn_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "libsrcnn_amd", "csrc"))
+                  if f.endswith((".cpp", ".hip", ".hpp", ".h")))
+    assert src.count("getenv(") == 1
+    # a child with switches set reports them; the parent's table is unaffected (read at load time)
+    code = "import sys; sys.path.insert(0, %r); import libsrcnn_amd as S; print(S.debug_settings())" % ROOT
+    child = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_CONV12_DMA="0", SRCNN_MAX_LANES="99", SRCNN_BANDS="0.5"),
+                           capture_output=True, text=True, check=True).stdout
+    assert "SRCNN_CONV12_DMA=0 (default 1)" in child and "SRCNN_MAX_LANES=64 (default 4)" in child and "SRCNN_BANDS=0.5" in child
+    rows = S.debug_settings(markdown=True).strip().splitlines()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    missing = [r for r in rows if r not in design]
+    assert not missing, "DESIGN.md section 6 is stale: run tools/gen_settings_table.py\n" + "\n".join(missing[:3])
 
 
 def test_reference_argument_checks_need_no_device(S):

@@ -291,8 +291,9 @@ def test_fast_tiers_through_processsrcnn_differ_by_at_most_one_level(srcnn, orac
     assert np.array_equal(out.reshape(want_rgb.shape), want_rgb) and np.array_equal(conv.reshape(want_conv.shape), want_conv)
 
 
-def test_unfused_f16_path_still_available(oracle_lib, tmp_path):
-    """SRCNN_F16_UNFUSED=1 selects the two-kernel form of the tier (k_conv12_f16 + k_conv3_fast) for A/B runs."""
+def test_f16_tier_in_a_fresh_process(oracle_lib, tmp_path):
+    """The fused fp16 tier (the only form since round 5: the two-kernel form k_conv12_f16 + k_conv3_fast is gone) from a
+    process of its own, inside its documented bound."""
     import os
     import subprocess
     import sys
@@ -301,7 +302,7 @@ def test_unfused_f16_path_still_available(oracle_lib, tmp_path):
             "from libsrcnn_amd import synth; S.init(0); S.set_mode(S.MODE_FAST_F16);"
             "y = synth.plane(70, 150, 11, 'noise');"
             "e = float(np.max(np.abs(S.y_upscale2x(y).astype(np.float64) - oracle.Oracle().y_path(y)))); print('ERR', e)") % root
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_F16_UNFUSED="1"), capture_output=True, text=True,
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True,
                        timeout=300)
     assert "ERR" in r.stdout, r.stdout + r.stderr
     err = float(r.stdout.split("ERR")[1])

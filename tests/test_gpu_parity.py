@@ -261,11 +261,12 @@ def test_host_stream_equals_singles(srcnn, use_graph):
         assert_bit_equal(got[i], srcnn.y_upscale2x(fr[i]), "frame %d (graph=%s)" % (i, use_graph))
 
 
-@pytest.mark.parametrize("env", [{"SRCNN_CONV12_VARIANT": "0"}, {"SRCNN_CONV12_VARIANT": "2"}, {"SRCNN_CONV12_VARIANT": "3"},
-                                 {"SRCNN_CONV12_VARIANT": "4", "SRCNN_CONV3_WDMA": "0"}, {"SRCNN_CONV12": "valu"}])
-def test_alternate_layer12_kernels_bit_exact(env, golden, tmp_path):
-    """The A/B variants of the layer-1+2 kernel (selected by environment at init, hence a subprocess) all
-    reproduce the golden output bit for bit."""
+@pytest.mark.parametrize("env", [{"SRCNN_CONV12_DMA": "0", "SRCNN_CONV3_WDMA": "0"}, {"SRCNN_CONV12_QUEUE": "0"},
+                                 {"SRCNN_CONV12_SPREAD": "0", "SRCNN_CONV3_OFF64": "1"}],
+                         ids=["no-dma-staging", "static-stride", "no-spread-64bit-offsets"])
+def test_fallback_layer_kernels_bit_exact(env, golden, tmp_path):
+    """The one fallback each layer kernel keeps (round 5: production + one fallback per kernel; the switches are read when
+    the library is loaded, hence a subprocess) reproduces the golden output bit for bit."""
     import os
     import subprocess
     import sys

@@ -1,6 +1,6 @@
 """Every resampler the library can select for a plane up-scale gives the same bits (GPU).
 
-The default is k_rs2d_dma (LDS-DMA patch prefetch); SRCNN_RS_DMA=0 selects k_rs2d<0>, SRCNN_RESAMPLE_OLD2D=1 the round-2
+The default is k_rs2d_dma (LDS-DMA patch prefetch); SRCNN_RS_DMA=0 selects k_rs2d<0>, SRCNN_RESAMPLE_2PASS=1 the generic
 fused kernel and SRCNN_RESAMPLE_2PASS=1 the two separate passes (the form that is closest to src/frawscale.cpp:238-385).
 The selection is read once at library load, hence one subprocess per selection; each prints a sha256 per case, and the
 default's output of the first cases is also compared with the oracle in this process.
@@ -66,7 +66,7 @@ def run_variant(env):
 
 def test_all_plane_resamplers_agree_bit_for_bit(srcnn, oracle_lib):
     base = run_variant({})
-    for env in ({"SRCNN_RS_DMA": "0"}, {"SRCNN_RESAMPLE_OLD2D": "1"}, {"SRCNN_RESAMPLE_2PASS": "1"}, {"SRCNN_RS_TPB": "1"},
+    for env in ({"SRCNN_RS_DMA": "0"}, {"SRCNN_RESAMPLE_2PASS": "1"}, {"SRCNN_RS_TPB": "1"},
                 {"SRCNN_RS_TPB": "3", "SRCNN_RS_DMA": "0"}):
         got = run_variant(env)
         assert got == base, "%r differs from the default resampler in cases %r" % (

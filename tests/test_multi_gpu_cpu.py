@@ -312,3 +312,34 @@ def test_gloo_world4_piecewise_gather_with_the_c_piece_table(geom, world, nsub, 
         assert p.exitcode == 0
     assert shape == (2 * geom[0], 2 * geom[1])
     assert ok, "pieces gathered with srcnn_tiled_piece's table do not assemble into the frame"
+
+
+def test_gather_table_does_not_depend_on_the_process_environment():
+    """ranks launched with different SRCNN_* switches must derive the SAME per-piece gather table (it used to
+    be planned on the layer-1+2 geometry the process had selected).  The switches are read when the library is loaded, so each
+    environment gets a process of its own; every one prints the table of 60 random (width, height, ranks, pieces) geometries."""
+    import hashlib
+    import subprocess
+    code = r"""
+import sys, ctypes as C, hashlib
+sys.path.insert(0, %r)
+import numpy as np, libsrcnn_amd as S
+L = S.lib(); rng = np.random.default_rng(11); h = hashlib.sha256()
+for _ in range(60):
+    out_h = int(rng.integers(64, 20000)); out_w = int(rng.integers(1, 20000)); world = int(rng.integers(1, 9)); nsub = int(rng.integers(1, 9))
+    for r in range(world):
+        for i in range(nsub):
+            a, n = C.c_uint(), C.c_uint()
+            assert L.srcnn_tiled_piece(out_w, out_h, r, world, i, nsub, C.byref(a), C.byref(n)) == 0
+            h.update(b"%%d,%%d;" %% (a.value, n.value))
+print("TABLE", h.hexdigest())
+""" % ROOT
+    envs = [{}, {"SRCNN_CONV12_DMA": "0"}, {"SRCNN_CONV12_QUEUE": "0", "SRCNN_CONV12_SPREAD": "0"},
+            {"SRCNN_CONV12_VARIANT": "3", "SRCNN_CONV12": "valu"},          # the round-4 switches that used to change the table
+            {"SRCNN_MAX_WORKSPACE_MB": "64", "SRCNN_RESAMPLE_2PASS": "1", "SRCNN_DEVICES": "0,0"}]
+    tables = set()
+    for e in envs:
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **e), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        tables.add([ln for ln in r.stdout.splitlines() if ln.startswith("TABLE")][0])
+    assert len(tables) == 1, tables
