@@ -353,7 +353,15 @@ int srcnn_comm_destroy(void)
             // communicator is aborted -- which ends the spinning kernels -- instead of destroyed.
             const int ms = g_timeout_ms.load();
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
-            std::vector<hipStream_t> streams = g_streams;
+            // only streams that are known to be alive: the NULL stream, the library's comm stream and streams from
+            // srcnn_stream_create that have not been destroyed since (querying a destroyed handle crashes inside the runtime);
+            // a caller that passed a raw HIP stream of its own drains it itself
+            std::vector<hipStream_t> streams;
+            {
+                std::lock_guard<std::mutex> gk(srcnn::G.mu);
+                for (hipStream_t st : g_streams)
+                    if (!st || srcnn::G.stream_ctx.count(st)) streams.push_back(st);
+            }
             if (g_comm_stream) streams.push_back(g_comm_stream);
             for (hipStream_t st : streams) {
                 for (int n = 0; drained; ++n) {
