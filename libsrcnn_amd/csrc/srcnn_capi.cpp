@@ -672,7 +672,18 @@ void run_conv12(const Call& c, const float* Y, int W, int H, int y_row_base, int
         clk = c.cx->clock_buf + 2 * (size_t)(c.cx->clock_n.fetch_add(1) % kClockSlots);
     // the tile queue lives with the workspace: one per stream, so launches that share it are ordered
     unsigned* queue = nullptr;
-    if (c.ws && settings().conv12_queue) {
+    // A capture that is not one of the library's own (those freeze a PRIVATE workspace first): the caller may replay the graph
+    // on any stream, beside eager calls that share this workspace's counters, and the probe slot would be baked in as well --
+    // such launches deal their tiles with the static stride and stamp nothing.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool foreign_capture = c.s && c.ws && !c.ws->frozen && hipStreamIsCapturing(c.s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+    if (foreign_capture) clk = nullptr;
+    if (c.ws && settings().conv12_queue && !foreign_capture) {
+        if (c.ws->queue && c.ws->queue_dirty) {
+            // a call on this workspace failed after launching: a launch that never finished leaves its draws behind
+            if (hipMemsetAsync(c.ws->queue, 0, 2 * sizeof(unsigned), c.s) == hipSuccess) c.ws->queue_dirty = false;
+            else (void)hipGetLastError();
+        }
         if (!c.ws->queue && !c.ws->frozen) {
             void* q = nullptr;
             // zeroed ON THE LAUNCH STREAM: lane streams are non-blocking, so a null-stream hipMemset is not ordered before
@@ -816,7 +827,10 @@ int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw
         launch_conv3(ws.c2, plane, (int)dw, (int)dh, (int)ca, (int)(cb - ca), d_out, (int)r0, (int)(r1 - r0),
                      c.relax(), c.s);
     }
-    HIP_TRY(hipGetLastError());
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess) {
+        ws.queue_dirty = true;                         // re-zeroed on the launch stream before the next launch trusts it
+        return fail(SRCNN_E_HIP, "y_path_rows: %s", hipGetErrorString(e));
+    }
     return SRCNN_OK;
 }
 

@@ -71,6 +71,7 @@ struct Workspace {          // scratch of one stream / graph / lane; grow-only
     float* planes = nullptr; size_t planes_n = 0; // colour shell: split planes / Y' / resized chroma planes
     unsigned char* bytes = nullptr; size_t bytes_n = 0;
     unsigned* queue = nullptr;                   // two words: the tile queue of k_conv12_mfma launches on this workspace's stream
+    bool queue_dirty = false;                    // a call failed after launching: zero the counters before the next launch
     bool frozen = false;    // a captured graph has these pointers baked in: growing is an error
     size_t footprint() const { return sizeof(float) * (tmp_n + up_n + c2_n + planes_n) + bytes_n; }
     void release()

@@ -15,6 +15,39 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
 
 
+# ---- what a green run covered -------------------------------------------------------------------------------------------
+# Some GPU tests rotate their inputs from run to run (whole-frame seeds, oracle-window positions, the stress pool).  A red run
+# prints its seed in the failure; a GREEN run used to leave no trace of what it had covered.  Every rotating value now goes
+# through rotating_seed(): ONE value per session (or SRCNN_TEST_SEED to replay), recorded per use, written to
+# gpurun_out/test_seeds.json when the session ends and echoed in pytest's last lines, so the tail of the log carries it.
+_SESSION_SEED = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(__import__("time").time()) & 0xFFFFF)
+_SEEDS_USED = {}
+
+
+def rotating_seed(what):
+    _SEEDS_USED[what] = _SESSION_SEED
+    return _SESSION_SEED
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _SEEDS_USED:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "test_seeds.json"), "w") as f:
+            json.dump({"session_seed": _SESSION_SEED, "replay": "SRCNN_TEST_SEED=%d" % _SESSION_SEED, "exitstatus": int(exitstatus),
+                       "used_by": sorted(_SEEDS_USED)}, f, indent=1)
+    except OSError:
+        pass
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if _SEEDS_USED:
+        terminalreporter.write_line("rotating inputs of this run: SRCNN_TEST_SEED=%d (%s) -> gpurun_out/test_seeds.json" %
+                                    (_SESSION_SEED, ", ".join(sorted(_SEEDS_USED))))
+
+
 @pytest.fixture(scope="session")
 def golden():
     class G:

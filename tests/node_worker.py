@@ -132,6 +132,37 @@ def cmd_node_tiled(nctx):
     return res
 
 
+def cmd_node_tiled_16k(nctx):
+    """BASELINE config #4 at its stated size, from ONE process: a 7680x4320 frame -> 15360x8640 dealt over `nctx` contexts
+    (srcnn_y_upscale2x_f32_node_dev: every context pulls its source rows from the root and pushes finished pieces back while
+    the next piece computes) == the whole-frame call, by sha256; plus oracle windows on the first and last seam."""
+    import time
+    res = {"contexts": S.init_devices(devices(nctx))}
+    L = S.lib()
+    h, w = 4320, 7680
+    y = synth.plane(h, w, synth.SEED0 + 4, "smooth")
+    d_in = S.DeviceBuffer.from_numpy(y)
+    d_out = S.DeviceBuffer(4 * h * w * 4)
+    S.check(L.srcnn_memset_dev(d_out.ptr, 0xFF, 4 * h * w * 4, None)); S.sync()
+    t0 = time.perf_counter()
+    S.check(L.srcnn_y_upscale2x_f32_node_dev(d_in.ptr, w, h, d_out.ptr, 4))
+    res["node_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    tiled = d_out.to_numpy(np.float32, (2 * h, 2 * w))
+    res["tiled_sha"] = sha(tiled)
+    orc = oracle.Oracle()
+    ok = []
+    for seam in (2 * h // nctx, 2 * h - 2 * h // nctx):          # windows across the first and the last band seam
+        iy0, iy1 = seam // 2 - 40, seam // 2 + 40
+        want = orc.y_path(np.ascontiguousarray(y[iy0:iy1, 1000:1200]))
+        got = tiled[seam - 30:seam + 30, 2000 + 40:2400 - 40]
+        ok.append(bool(np.array_equal(got.view(np.uint32), want[2 * 40 - 30 + 0:2 * 40 + 30, 40:-40].view(np.uint32))))
+    res["seam_windows_vs_oracle"] = ok
+    del tiled
+    S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, w, h, d_out.ptr, None)); S.sync()
+    res["whole_sha"] = sha(d_out.to_numpy(np.float32, (2 * h, 2 * w)))
+    return res
+
+
 def cmd_stream(nctx):
     """Host-frame stream dealt over the contexts == frame-by-frame results."""
     res = {"contexts": S.init_devices(devices(nctx))}

@@ -1,0 +1,74 @@
+"""GPU: BASELINE.json configs #4 and #5 at their STATED counts (missing #3 / next item 6).
+  #5  "stream of 512 4K frames ... per-GPU hipGraph capture": 512 frames of 3840x2160 -> 7680x4320 through
+      srcnn_y_upscale2x_f32_stream(use_graph = 1), from a pool of 8 page-locked inputs into a ring of 8 page-locked outputs;
+      every 64th frame is compared with the single-frame call, one of them with an oracle window; host memory and thread
+      count must be flat over the run.
+  #4  "single 8K frame tiled across 8 MI355X": one 7680x4320 frame -> 15360x8640 over 8 contexts of one process (node call),
+      sha256-equal to the whole-frame call.  The one-process-per-GPU form of the same frame runs at world 2/3/5 in
+      tests/test_gpu_comm_ranks.py (a box allows 6 processes on its card, so 8 ranks cannot be started there).
+The reference has one entry point and no notion of either (src/libsrcnn.cpp:943-1064); parity is frame-by-frame as ever."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from libsrcnn_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config5_512_frames_streamed_with_hipgraph_replay(srcnn, oracle_lib):
+    import psutil
+    from test_gpu_configs import check_windows
+    S, L = srcnn, srcnn.lib()
+    h, w, POOL, CALLS = 2160, 3840, 8, 64                     # 64 calls x 8 frames = 512 frames
+    pin_in = S.PinnedArray((POOL, h, w), np.float32)
+    pin_out = S.PinnedArray((POOL, 2 * h, 2 * w), np.float32)
+    base = [synth.plane(h, w, synth.SEED0 + 900 + k, "smooth" if k % 2 else "noise") for k in range(2)]
+    for k in range(POOL):
+        pin_in.array[k] = np.roll(base[k & 1], 37 * k, axis=1)
+    proc = psutil.Process()
+    checked = 0
+    rss0 = thr0 = kept = None
+    try:
+        for c in range(CALLS):
+            # the pool is refilled as a real feeder would: slot c % 8 gets a new frame before every call
+            slot = c % POOL
+            pin_in.array[slot] = np.roll(base[c & 1], 11 * c + 5, axis=0)
+            S.check(L.srcnn_y_upscale2x_f32_stream(pin_in.ptr, w, h, POOL, pin_out.ptr, 1))
+            if c % 8 == 0:                                     # frame index 8*c is a multiple of 64: slot 0 of this call
+                src = np.array(pin_in.array[0])
+                got = np.array(pin_out.array[0])
+                assert_bit_equal(got, S.y_upscale2x(src), "frame %d of the 512-frame stream vs the single-frame call" % (8 * c))
+                if c == 32:
+                    kept = (src, got)                          # checked against the oracle after the loop: its OpenMP team
+                checked += 1                                   # would otherwise show up in the thread count below
+            if c == 8:
+                rss0, thr0 = proc.memory_info().rss, proc.num_threads()
+        rss1, thr1 = proc.memory_info().rss, proc.num_threads()
+    finally:
+        pin_in.free(); pin_out.free()
+    assert checked == 8
+    check_windows(oracle_lib, kept[0], kept[1], [(0, 0, 40, 64), (2 * h - 40, 2 * w - 64, 40, 64), (2111, 3001, 48, 96)],
+                  "frame 256 of the stream")
+    assert thr1 <= thr0, (thr0, thr1)                          # no thread leaked per call / per replay
+    assert rss1 - rss0 < 96 << 20, (rss0, rss1)                # no per-frame host growth (8 x 133 MB frames pass through per call)
+
+
+def test_config4_16k_frame_over_8_contexts_of_one_process():
+    worker = os.path.join(ROOT, "tests", "node_worker.py")
+    e = dict(os.environ)
+    e.pop("SRCNN_DEVICES", None)
+    r = subprocess.run([sys.executable, worker, "node_tiled_16k", "8"], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["contexts"] == 8
+    assert res["tiled_sha"] == res["whole_sha"], res
+    assert all(res["seam_windows_vs_oracle"]), res

@@ -40,14 +40,15 @@ def check_windows(oracle_lib, y, frame, windows, what):
 
 # Window positions rotate from run to run (the fixed borders / seams stay): the per-run salt is printed once so that a
 # failure can be replayed with SRCNN_TEST_SEED=<salt>.
-import os as _os
-import time as _time
-RUN_SALT = int(_os.environ.get("SRCNN_TEST_SEED", "0")) or (int(_time.time()) & 0xFFFFF)
-print("test_gpu_configs: window salt", RUN_SALT)
+from conftest import rotating_seed
+
+
+def run_salt():
+    return rotating_seed("oracle-window positions of the full-size configuration tests")
 
 
 def frame_windows(out_h, out_w, seams, seed, n_random=2):
-    rng = np.random.default_rng([seed, RUN_SALT])
+    rng = np.random.default_rng([seed, run_salt()])
     wins = [(0, 0, 40, 64), (out_h - 40, out_w - 64, 40, 64), (0, out_w - 64, 24, 64), (out_h - 24, 0, 24, 64)]
     for s in seams:                       # a window straddling each seam, at a seeded x
         ox = int(rng.integers(0, out_w - 96))

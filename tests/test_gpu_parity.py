@@ -531,7 +531,8 @@ def test_whole_1080p_frame_against_the_compiled_reference(srcnn):
     import time
     import oracle
     eng = oracle.Reference() if oracle.have_reference() else oracle.Oracle()
-    seed = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(time.time()) & 0xFFFFF)
+    from conftest import rotating_seed
+    seed = rotating_seed("whole 1080p frame vs the compiled reference")
     print("whole-frame seed", seed, "engine", type(eng).__name__)
     y = synth.plane(1080, 1920, synth.SEED0 + seed, "noise" if seed & 1 else "smooth")
     want = eng.y_path(y)
@@ -550,7 +551,8 @@ def test_whole_4k_frame_every_sample_vs_reference(srcnn):
     import time
     import oracle
     eng = oracle.Reference() if oracle.have_reference() else oracle.Oracle()
-    seed = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(time.time()) & 0xFFFFF)
+    from conftest import rotating_seed
+    seed = rotating_seed("whole 4K->8K frame, every sample, vs the compiled reference")
     h, w = 2160, 3840
     y = synth.plane(h, w, synth.SEED0 + 7 * seed + 1, "smooth" if seed & 1 else "noise")
     got = srcnn.y_upscale2x(y)

@@ -21,7 +21,12 @@ CASES = [
     ("dma-no-quarter-spread", {"SRCNN_CONV12_SPREAD": "0"}, 4000),
     ("no-dma-staging", {"SRCNN_CONV12_DMA": "0", "SRCNN_CONV3_WDMA": "0"}, 4000),
 ]
-SEED = int(os.environ.get("SRCNN_TEST_SEED", "0")) or (int(time.time()) & 0xFFFFF)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import rotating_seed          # noqa: E402
+
+
+def stress_seed():
+    return rotating_seed("stress pool of small shapes")
 
 
 @pytest.fixture(scope="module")
@@ -30,13 +35,13 @@ def pool_file(tmp_path_factory):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import stress_worker
     path = str(tmp_path_factory.mktemp("stress") / "pool.npz")
-    stress_worker.save_pool(path, 40, SEED)
+    stress_worker.save_pool(path, 40, stress_seed())
     return path
 
 
 @pytest.mark.parametrize("name,env,iters", CASES, ids=[c[0] for c in CASES])
 def test_small_shape_launches_interleaved_with_h2d_copies(name, env, iters, pool_file):
-    seed = SEED
+    seed = stress_seed()
     e = dict(os.environ)
     e.pop("SRCNN_DEVICES", None)
     e.update(env)
