@@ -51,7 +51,9 @@ def test_config5_512_frames_streamed_with_hipgraph_replay(srcnn, oracle_lib):
                     kept = (src, got)                          # checked against the oracle after the loop: its OpenMP team
                 checked += 1                                   # would otherwise show up in the thread count below
             if c == 8:
-                rss0, thr0 = proc.memory_info().rss, proc.num_threads()
+                thr0 = proc.num_threads()
+            if c == 33:                                        # (after `kept` took its 166 MB)
+                rss0 = proc.memory_info().rss
         rss1, thr1 = proc.memory_info().rss, proc.num_threads()
     finally:
         pin_in.free(); pin_out.free()
@@ -59,7 +61,7 @@ def test_config5_512_frames_streamed_with_hipgraph_replay(srcnn, oracle_lib):
     check_windows(oracle_lib, kept[0], kept[1], [(0, 0, 40, 64), (2 * h - 40, 2 * w - 64, 40, 64), (2111, 3001, 48, 96)],
                   "frame 256 of the stream")
     assert thr1 <= thr0, (thr0, thr1)                          # no thread leaked per call / per replay
-    assert rss1 - rss0 < 96 << 20, (rss0, rss1)                # no per-frame host growth (8 x 133 MB frames pass through per call)
+    assert rss1 - rss0 < 96 << 20, (rss0, rss1)                # no per-frame host growth over the last 240 frames (8 x 133 MB pass through per call)
 
 
 def test_config4_16k_frame_over_8_contexts_of_one_process():
