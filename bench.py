@@ -647,7 +647,7 @@ def traffic_record():
     figure is held to its own fingerprint."""
     from libsrcnn_amd import build as _b
     now = _b.kernel_source_sha("k_conv12_mfma")
-    for name in ("r04_pmc_conv12.json", "r03_pmc_conv12.json", "r02_pmc_conv12.json", "pmc_conv12.json"):
+    for name in ("r05_pmc_conv12.json", "r04_pmc_conv12.json", "r03_pmc_conv12.json", "r02_pmc_conv12.json", "pmc_conv12.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -792,7 +792,12 @@ def main():
                        "frames_per_gpu_per_step": F, "in": [IN_W, IN_H], "out": [2 * IN_W, 2 * IN_H], "mode": args.tier,
                        "parallelism": "frames sharded %d-way, no data-path collective" % world},
             "roofline": {"kernel": "k_conv12_mfma (conv 9x9x1->64 + ReLU + conv 1x1x64->32 + ReLU)",
-                         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "bound": "mfma",
+                         "bound_detail": "fp32 issue: per tap-step a wave pays 64 cycles of v_mfma_f32_32x32x1_2b_f32 (the rounded "
+                                         "products) plus ~80 of v_pk_add_f32 (the rounded sums) and the two do not overlap on gfx950 "
+                                         "(profiles/r01_mfma_coissue.txt): the binding resource is the SIMD's serialised MFMA + VALU issue, "
+                                         "not the matrix pipe alone",
+                         "achieved": round(achieved, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_from": traffic_from,
                          "frac_of_no_fma_ceiling": round(achieved / (PEAK_F32_TFLOPS / 2), 4),
                          "avg_launch_ms": round(avg12, 4), "launches": int(c12_n),
