@@ -213,3 +213,69 @@ def test_pinned_staging_leaves_the_callers_memory_policy_alone(srcnn):
         assert _mempolicy() == before
     finally:
         libc.syscall(238, mode0, None, C.c_ulong(0))
+
+
+# ---- round 5: the asynchronous pair's ownership and mode rules ----
+def _rgb(h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = synth.plane(h, w, synth.SEED0 + seed, "smooth")
+    img = np.empty((h, w, 3), np.uint8)
+    for k in range(3):
+        img[..., k] = np.clip(base * (0.55 + 0.15 * k) + rng.integers(0, 40, base.shape), 0, 255).astype(np.uint8)
+    return img
+
+
+def test_async_job_takes_the_mode_in_force_at_begin(srcnn, oracle_lib):
+    """srcnn_amd.h: the numerics mode is sampled when a call STARTS.  For the asynchronous pair that is srcnn_process_u8_begin
+    -- it used to be whenever the worker thread got going, so a srcnn_set_mode right behind begin() changed an image in
+    flight.  A large image (tens of ms of work) is begun in STRICT, the mode is switched to FAST_F16 at once, and the result must
+    still be the reference's bytes; the next job then gets the new mode."""
+    S = srcnn
+    img = _rgb(1080, 1920, 91)
+    want_rgb, want_conv = oracle_lib.process(_rgb(64, 96, 91), 2.0)      # (small oracle case for the second half)
+    strict_rgb, strict_conv = S.process_u8(img, 2.0)
+    prev = S.set_mode(S.MODE_STRICT)
+    try:
+        for _ in range(3):
+            job = S.ProcessJob(img, 2.0)
+            S.set_mode(S.MODE_FAST_F16)                                  # right behind begin(): must not touch the job
+            out, conv = job.result()
+            S.set_mode(S.MODE_STRICT)
+            assert np.array_equal(out, strict_rgb) and np.array_equal(conv, strict_conv)
+        S.set_mode(S.MODE_FAST_F16)
+        job = S.ProcessJob(img, 2.0)
+        S.set_mode(S.MODE_STRICT)
+        out, _ = job.result()
+        d = np.abs(out.astype(np.int16) - strict_rgb.astype(np.int16))
+        assert int(d.max()) <= 1 and 0 < int((d > 0).sum())             # the non-parity tier did run for THAT job
+    finally:
+        S.set_mode(prev)
+    got_rgb, got_conv = S.process_u8(_rgb(64, 96, 91), 2.0)
+    assert np.array_equal(got_rgb, want_rgb) and np.array_equal(got_conv, want_conv)
+
+
+def test_dropped_async_jobs_are_joined_before_their_buffers_go(srcnn):
+    """A ProcessJob that is dropped without result() -- e.g. the second constructor of [ProcessJob(a), ProcessJob(b)] raising --
+    must not let its numpy buffers be reclaimed under the native worker thread: the finaliser waits for the job.  Jobs are
+    begun and dropped at once, over and over, with fresh garbage allocated in between; then a normal call still gives the
+    reference-equal result of the blocking call."""
+    import gc
+    S = srcnn
+    img = _rgb(1080, 1920, 92)
+    want = S.process_u8(img, 2.0)
+    for i in range(12):
+        job = S.ProcessJob(img.copy(), 2.0)
+        del job                                                          # no result(): the finaliser must join the worker
+        gc.collect()
+        junk = [np.full(1 << 20, i, np.uint8) for _ in range(8)]         # reuse of the freed pages, if anything was freed early
+        del junk
+    with S.ProcessJob(img, 2.0) as job:
+        pass                                                             # __exit__ joins
+    assert job.job is None
+    got = S.ProcessJob(img, 2.0).result()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    with pytest.raises(Exception):
+        [S.ProcessJob(img, 2.0), S.ProcessJob(np.zeros((4, 4), np.uint8), 2.0)]      # second constructor raises (2-D array)
+    gc.collect()
+    got = S.process_u8(img, 2.0)
+    assert np.array_equal(got[0], want[0])
