@@ -204,22 +204,33 @@ def process_srcnn_wall(S):
             "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
             "note": "srcnn_process_u8, source and result allocated with srcnn_host_alloc_pinned, blocking calls back to back"}
         same = bool(np.array_equal(pins[0].array, res))
-        n_img, jobs = 16, []
-        t0 = time.perf_counter()
-        for i in range(n_img):
-            j = C.c_void_p()
-            rc = L.srcnn_process_u8_begin(pin_img.array.ctypes.data, w, h, 3, 2.0, 2, pins[i & 1].array.ctypes.data, None, C.byref(j))
-            assert rc == 0, rc
-            jobs.append(j)
-            if len(jobs) == 2:
+        def sequence(n_img):
+            jobs = []
+            t0 = time.perf_counter()
+            for i in range(n_img):
+                j = C.c_void_p()
+                rc = L.srcnn_process_u8_begin(pin_img.array.ctypes.data, w, h, 3, 2.0, 2, pins[i & 1].array.ctypes.data, None, C.byref(j))
+                assert rc == 0, rc
+                jobs.append(j)
+                if len(jobs) == 2:
+                    assert L.srcnn_process_u8_wait(jobs.pop(0)) == 0
+            while jobs:
                 assert L.srcnn_process_u8_wait(jobs.pop(0)) == 0
-        while jobs:
-            assert L.srcnn_process_u8_wait(jobs.pop(0)) == 0
-        per = (time.perf_counter() - t0) / n_img
+            return (time.perf_counter() - t0) / n_img
+        # Round 5: the figure used to be ONE cold sequence of 16 images, and it came out 10.2 or 12.4 ms depending on the box:
+        # the second job in flight needs a second lane (streams, scratch, staging), which the blocking calls before it never
+        # created -- tens of milliseconds of one-off allocation inside a 160 ms measurement.  Now: the first sequence is
+        # reported as what it is (cold), then three more; the figure is their best, the spread is in the line.
+        n_img = 16
+        cold = sequence(n_img)
+        warm = [sequence(n_img) for _ in range(3)]
+        per = min(warm)
         out["3840x2160_rgb_async_sequence"] = {
             "ms_per_image": round(per * 1e3, 2), "MPix/s": round(4 * h * w / 1e6 / per, 1), "images": n_img,
+            "sequences_ms_per_image": [round(t * 1e3, 2) for t in warm], "first_cold_sequence_ms_per_image": round(cold * 1e3, 2),
             "results_equal_blocking_call": bool(same and np.array_equal(pins[1].array, res) and np.array_equal(pins[0].array, res)),
-            "note": "srcnn_process_u8_begin/_wait, two jobs in flight, kernels chained on the device, page-locked buffers"}
+            "note": "srcnn_process_u8_begin/_wait, two jobs in flight, kernels chained on the device, page-locked buffers; best of "
+                    "three 16-image sequences after one cold sequence (which creates the second lane: streams, scratch, staging)"}
     finally:
         pin_img.free()
         for p in pins:
