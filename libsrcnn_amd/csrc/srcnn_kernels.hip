@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_rs2d(const Rs2dArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- horizontal pass (same as k_resample_rows_reg), four columns per lane, then the sink ----
+        // ---- horizontal pass (same taps, same order as k_resample_rows), four columns per lane, then the sink ----
         if (x < a.dst_w) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {

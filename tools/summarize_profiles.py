@@ -44,10 +44,10 @@ def short(name):
     if "k_rs2d<" in name:
         kind = name.split("k_rs2d<")[1].split(",")[0].strip()
         return {"0": "k_rs2d [plane -> plane]", "1": "k_rs2d [RGB -> upscaled Y]", "2": "k_rs2d [fused chroma resample + colour merge]"}.get(kind, "k_rs2d")
-    for key in ("k_fused_f16", "k_conv12_f16", "k_conv12_mfma", "k_conv12", "k_conv3_fast", "k_conv3", "k_resample_2d", "k_resample_rows", "k_resample_cols", "k_rgb_split",
+    for key in ("k_fused_f16", "k_conv12_mfma", "k_conv3_fast", "k_conv3", "k_resample_rows", "k_resample_cols", "k_rgb_split",
                 "k_ycc_merge"):
         if key in name:
-            return key + (" [fast tier]" if key in ("k_fused_f16", "k_conv12_f16", "k_conv3_fast") else tier)
+            return key + (" [fast tier]" if key in ("k_fused_f16", "k_conv3_fast") else tier)
     return name[:40]
 
 
