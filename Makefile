@@ -17,7 +17,7 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fvisib
             -Wno-unused-result -Wno-unused-value -Wno-ignored-attributes -D__HIP_PLATFORM_AMD__
 SRCS    := srcnn_kernels.hip srcnn_fused_f16.hip srcnn_capi.cpp srcnn_pipeline.cpp srcnn_comm.cpp dropin.cpp
 OBJS    := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(basename $(SRCS))))
-HDRS    := $(CSRC)/srcnn_kernels.h $(CSRC)/srcnn_host.hpp $(CSRC)/srcnn_settings.hpp $(CSRC)/resample_table.hpp $(CSRC)/srcnn_weights.inc include/srcnn_amd.h include/libsrcnn_dropin.h
+HDRS    := $(CSRC)/srcnn_kernels.h $(CSRC)/srcnn_host.hpp $(CSRC)/srcnn_settings.hpp $(CSRC)/srcnn_watchdog.hpp $(CSRC)/resample_table.hpp $(CSRC)/srcnn_weights.inc include/srcnn_amd.h include/libsrcnn_dropin.h
 
 PREFIX  ?= /usr/local
 ROCM    ?= /opt/rocm
@@ -75,7 +75,7 @@ gpu-test: all oracle
 
 # CPU-only sanitizer builds of the host code (no GPU sanitizer exists on this pool): tests/host/host_sanitize.cpp
 SAN_SRCS := tests/host/host_sanitize.cpp $(CSRC)/dropin.cpp
-SAN_DEPS := $(SAN_SRCS) $(CSRC)/resample_table.hpp oracle/srcnn_oracle.c include/srcnn_amd.h include/libsrcnn_dropin.h
+SAN_DEPS := $(SAN_SRCS) $(CSRC)/resample_table.hpp $(CSRC)/srcnn_watchdog.hpp oracle/srcnn_oracle.c include/srcnn_amd.h include/libsrcnn_dropin.h
 tests/host/_build/oracle_%.o: oracle/srcnn_oracle.c oracle/oracle_weights.inc
 	@mkdir -p tests/host/_build
 	gcc -O1 -g -ffp-contract=off -std=c99 -fsanitize=$(subst asan,address$(comma)undefined,$(subst tsan,thread,$*)) -fno-omit-frame-pointer -c $< -o $@

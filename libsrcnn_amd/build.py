@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrcnn_amd.so")
 
 SOURCES = ["srcnn_kernels.hip", "srcnn_fused_f16.hip", "srcnn_capi.cpp", "srcnn_pipeline.cpp", "srcnn_comm.cpp", "dropin.cpp"]
-DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "srcnn_host.hpp", "srcnn_settings.hpp", "resample_table.hpp", "srcnn_weights.inc",
+DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "srcnn_host.hpp", "srcnn_settings.hpp", "srcnn_watchdog.hpp", "resample_table.hpp", "srcnn_weights.inc",
                   "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h", "exports.map"]
 
 # -ffp-contract=off: strict kernels and the host table builder must round every multiply and add

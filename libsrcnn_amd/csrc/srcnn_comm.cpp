@@ -23,6 +23,7 @@
 #include "../../include/srcnn_amd.h"
 
 #include "srcnn_host.hpp"
+#include "srcnn_watchdog.hpp"
 
 namespace {
 
@@ -84,66 +85,14 @@ void abort_comm(ncclComm_t comm, unsigned gen)
     if (R.CommAbort && comm) (void)R.CommAbort(comm);
 }
 
-class Watchdog {
-public:
-    // arm() .. disarm() brackets one blocking call.  arm() returns whether a deadline is running -- the caller hands that back to
-    // disarm(), so a thread whose arm() was a no-op (no deadline configured at that moment) never touches another thread's
-    // region.  One armed region at a time: a second thread's RCCL call waits in arm() until the first has returned (or its
-    // deadline has aborted the communicator) -- the regions are host-side queueing calls, microseconds long unless a peer is missing.
-    bool arm(ncclComm_t comm, unsigned gen)
-    {
-        const int ms = g_timeout_ms.load();
-        if (ms <= 0) return false;
-        region_.lock();
-        std::lock_guard<std::mutex> lk(m_);
-        if (!started_) { th_ = std::thread([this] { run(); }); th_.detach(); started_ = true; }
-        comm_ = comm; gen_ = gen; fired_ = false; armed_ = true;
-        deadline_ = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
-        cv_.notify_all();
-        return true;
-    }
-    bool disarm(bool armed)                   // true: the deadline hit (the communicator is poisoned and being aborted)
-    {
-        if (!armed) return false;
-        bool fired;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            armed_ = false;
-            fired = fired_;
-            cv_.notify_all();
-        }
-        region_.unlock();
-        return fired;
-    }
-private:
-    void run()
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        for (;;) {
-            cv_.wait(lk, [&] { return armed_; });
-            while (armed_ && cv_.wait_until(lk, deadline_) != std::cv_status::timeout) {}
-            if (armed_ && std::chrono::steady_clock::now() >= deadline_) {
-                fired_ = true; armed_ = false;
-                const ncclComm_t c = comm_;
-                const unsigned gen = gen_;
-                // poisoned BEFORE m_ is dropped: an owner whose RCCL call returns right now sees fired_ under m_ and, whatever it
-                // calls next, a poisoned communicator -- never a healthy-looking one with an abort about to start
-                if (gen == g_gen.load()) g_poisoned = true;
-                lk.unlock();
-                abort_comm(c, gen);
-                lk.lock();
-            }
-        }
-    }
-    std::mutex m_, region_;
-    std::condition_variable cv_;
-    std::thread th_;
-    bool started_ = false, armed_ = false, fired_ = false;
-    ncclComm_t comm_ = nullptr;
-    unsigned gen_ = 0;
-    std::chrono::steady_clock::time_point deadline_;
+// (csrc/srcnn_watchdog.hpp: HIP-free, so the same class runs under ThreadSanitizer in tests/host/)
+struct CommWatchdog {
+    srcnn::Watchdog w{[](unsigned gen) { if (gen == g_gen.load()) g_poisoned = true; },
+                      [](void* comm, unsigned gen) { abort_comm(static_cast<ncclComm_t>(comm), gen); }};
+    bool arm(ncclComm_t comm, unsigned gen) { return w.arm(comm, gen, g_timeout_ms.load()); }
+    bool disarm(bool armed) { return w.disarm(armed); }
 };
-Watchdog& watchdog() { static Watchdog* w = new Watchdog; return *w; }      // (never destroyed: its thread outlives main)
+CommWatchdog& watchdog() { static CommWatchdog* w = new CommWatchdog; return *w; }      // (never destroyed: its thread outlives main)
 
 // everything queued on `s` has completed, or the deadline passed (then the communicator is aborted): hipSuccess / hipErrorNotReady
 hipError_t wait_stream_deadline(hipStream_t s, ncclComm_t comm, unsigned gen)

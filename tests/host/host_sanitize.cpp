@@ -9,7 +9,10 @@
 //     loop, new[] ownership of intermediates and results) with srcnn_process_u8 -- the one device call it makes --
 //     replaced by a stand-in that forwards to the CPU oracle.  The stand-in exists only in this test binary;
 //   * oracle/srcnn_oracle.c itself on odd plane shapes;
-//   * concurrent ProcessSRCNN calls from 4 threads (the TSan target: the drop-in keeps no per-call state).
+//   * concurrent ProcessSRCNN calls from 4 threads (the TSan target: the drop-in keeps no per-call state);
+//   * libsrcnn_amd/csrc/srcnn_watchdog.hpp  (the deadline around every blocking RCCL call) hammered from 4 threads, some of
+//     them toggling the timeout to 0 between calls: regions are exclusive, a no-op arm() never releases somebody else's region,
+//     a region that outlives its deadline is marked (under the lock) and aborted exactly once, stale generations are ignored.
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +24,7 @@
 #include "../../include/libsrcnn_dropin.h"
 #include "../../include/srcnn_amd.h"
 #include "../../libsrcnn_amd/csrc/resample_table.hpp"
+#include "../../libsrcnn_amd/csrc/srcnn_watchdog.hpp"
 
 extern "C" {
 int oracle_axis_window(int filter, unsigned dst_len, unsigned src_len);
@@ -177,12 +181,54 @@ static void check_threads()
     CHECK(bad == 0, "%d concurrent calls went wrong", bad.load());
 }
 
+static void check_watchdog()
+{
+    // (everything the watchdog's detached thread can touch lives for ever, as in the product, where the watchdog is a leaked singleton)
+    static std::atomic<int> marks{0}, aborts{0}, inside{0}, overlap{0};
+    static std::atomic<unsigned> current_gen{1};
+    static srcnn::Watchdog& wd = *new srcnn::Watchdog([](unsigned gen) { if (gen == current_gen.load()) ++marks; },
+                                                      [](void*, unsigned gen) { if (gen == current_gen.load()) ++aborts; });
+    std::atomic<int> timeout{30};
+    std::atomic<int> fired_seen{0}, slow_regions{0};
+    auto worker = [&](int id) {
+        for (int it = 0; it < 200; ++it) {
+            if (id == 3 && (it % 7) == 0) timeout = timeout.load() ? 0 : 30;          // a thread that switches the deadline off and on
+            int dummy = 0;
+            const bool armed = wd.arm(&dummy, current_gen.load(), timeout.load());
+            if (armed) {
+                if (inside.fetch_add(1) != 0) ++overlap;                              // armed regions must be exclusive
+                const bool slow = id == 0 && (it % 50) == 49;                         // a "blocked RCCL call": outlives its deadline
+                if (slow) { ++slow_regions; std::this_thread::sleep_for(std::chrono::milliseconds(80)); }
+                inside.fetch_sub(1);
+            }
+            if (wd.disarm(armed)) ++fired_seen;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < 4; ++i) th.emplace_back(worker, i);
+    for (auto& t : th) t.join();
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    CHECK(overlap.load() == 0, "watchdog: %d overlapping armed regions", overlap.load());
+    CHECK(fired_seen.load() == slow_regions.load(), "watchdog: %d regions outlived their deadline, %d saw it", slow_regions.load(), fired_seen.load());
+    CHECK(marks.load() == slow_regions.load() && aborts.load() == slow_regions.load(), "watchdog: marks %d aborts %d for %d slow regions",
+          marks.load(), aborts.load(), slow_regions.load());
+    // a stale generation: the region was armed for communicator generation 1, the communicator is replaced while it blocks
+    int dummy = 0;
+    const int m0 = marks.load(), a0 = aborts.load();
+    const bool armed = wd.arm(&dummy, 1, 20);
+    current_gen = 2;
+    std::this_thread::sleep_for(std::chrono::milliseconds(60));
+    CHECK(wd.disarm(armed), "watchdog: the stale region's deadline still fires for its owner");
+    CHECK(marks.load() == m0 && aborts.load() == a0, "watchdog: a stale generation must not touch the new communicator");
+}
+
 int main()
 {
     check_tables();
     check_oracle_shapes();
     check_dropin();
     check_threads();
+    check_watchdog();
     if (g_fail) { fprintf(stderr, "host_sanitize: %d check(s) failed\n", g_fail); return 1; }
     printf("host_sanitize: all checks passed (%d stand-in device calls)\n", g_calls.load());
     return 0;
