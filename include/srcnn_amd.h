@@ -84,7 +84,8 @@ extern "C" {
  *     context (env SRCNN_MAX_LANES) run concurrently, further callers wait for a lane.
  *   - *_dev calls take their scratch from the given stream's workspace; two threads using the SAME stream are
  *     serialised while they enqueue, different streams are independent.
- *   - The numerics mode is sampled once when a call starts; srcnn_set_mode never affects a call in flight.
+ *   - The numerics mode is sampled once when a call starts (for the asynchronous pair: in srcnn_process_u8_begin); srcnn_set_mode
+ *     never affects a call in flight.
  *   - srcnn_stream_destroy / srcnn_batch_graph_destroy / srcnn_shutdown must not race with calls that still use
  *     that stream / graph / the library (as with any handle).
  *
