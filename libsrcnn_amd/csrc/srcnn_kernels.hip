@@ -404,6 +404,15 @@ __device__ __forceinline__ void rs_dma_dword(const float* gsrc, const float* lds
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// The same with "uniform base (SGPR pair) + per-lane 32-bit byte offset" addressing: no 64-bit address arithmetic on the VALU.
+__device__ __forceinline__ void rs_dma_dword_s(const void* sbase, unsigned voff, const float* lds_dst)
+{
+    unsigned keep;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+
 // wave-uniform table entries through the scalar cache (the tables are written long before any launch that reads them)
 __device__ __forceinline__ int rs_sload(const int* p, int i)
 {
@@ -871,22 +880,35 @@ __global__ __launch_bounds__(64 * M_NW, 4) void k_conv12_mfma(
 // the arithmetic of chunk c and land in LDS after it.  All staging index math is shifts/compares
 // (no div/mod): 64 body columns by (lane, wave) and the 4 halo columns by a second small pass.
 // =============================================================================================
-constexpr int C3_TW = 64, C3_TH = 16, C3_MC = 4;
+constexpr int C3_TW = 64, C3_TH = 16;
 constexpr int C3_LW = C3_TW + 4, C3_LH = C3_TH + 4;
 constexpr int C3_CH = C3_LH * C3_LW;               // floats per staged channel
 static_assert(C3_LH % 4 == 0, "row slots");
-constexpr int C3_BODY = C3_MC * C3_LH / 4;         // body loads per thread per chunk (4 row slots)
-constexpr int C3_HALO = (C3_MC * C3_LH * 4 + 255) / 256;
+// channels per double-buffered LDS stage: 2 with DMA staging (25.6 KB of LDS and 76 VGPRs: six workgroups per CU), 4 with
+// register staging (47.4 KB: three)
+constexpr int c3_mc(bool sdma) { return sdma ? 2 : 4; }
 
 // X64 (experiment, SRCNN_MODE_RELAXED bit 2): the products are formed exactly -- v_fma_f64 on widened operands -- instead of
 // being rounded to fp32 first; everything else (per-channel fp64 sum in window order, fp32 running sum over the channels,
 // bias, clamp) is the reference's.  Per channel and lane 40 v_cvt_f64_f32 + 100 v_fma_f64 instead of 50 v_pk_mul_f32 +
 // 104 v_cvt_f64_f32 + 100 v_add_f64.
-template <bool STRICT, bool OFF64 = false, bool X64 = false>
-__global__ __launch_bounds__(256) void k_conv3(
+// SDMA (round 6, the production form of the strict kernel): the 64 body columns of every staged row go global -> LDS by
+// LDS-DMA ("uniform plane base + per-lane 32-bit offset" addressing: no VGPR destination, no ds_write, no address arithmetic
+// on the VALU); only the 4 halo columns still pass through registers; the lane's window is read from two fixed LDS row bases.
+// What that buys is REGISTERS, not instructions: at the old 4-channel stage the kernel ran no faster with 30 fewer index /
+// staging instructions per chunk (2.33 vs 2.30 ms, profiles/r06_conv3_ab.txt -- they were hidden, as the v_movs of round 2
+// had been), but at 76 VGPRs and 2-channel stages (25.6 KB of LDS) six workgroups fit a CU instead of three, and v_cvt_f64_f32
+// / v_add_f64 issue closer to their rate with six waves per SIMD: 2.24 vs 2.30 ms per 8K frame, the whole path -1 %.
+// 1-channel stages (32 barriers per tile) and 7-8 waves per SIMD (spills) are slower: 3.1 / 5.4 / 8.3 ms.
+// SDMA = false (SRCNN_CONV3_WDMA=0): the register-staged 4-channel form it replaced.
+template <bool STRICT, bool OFF64 = false, bool X64 = false, bool SDMA = false>
+__global__ __launch_bounds__(256, SDMA ? 6 : 1) void k_conv3(
     const float* __restrict__ C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows,
     float* __restrict__ out, int out_row0, int out_rows, int weights_by_dma)
 {
+    constexpr int C3_MC = c3_mc(SDMA);
+    constexpr int C3_BODY = C3_MC * C3_LH / 4;         // body loads per thread per chunk (4 row slots)
+    constexpr int C3_HALO = (C3_MC * C3_LH * 4 + 255) / 256;
     __shared__ float tile[2][C3_MC * C3_CH];
     // strict: [m][dy][6]: (w0,w1) (w2,w3) w4 pad -- packed-operand order;  X64: [m][dy][dx] as doubles
     __shared__ __attribute__((aligned(16))) float w3s[X64 ? C2N * 50 : C2N * 30];
@@ -902,7 +924,7 @@ __global__ __launch_bounds__(256) void k_conv3(
         // the packed weight image exists in constant memory as such (filled on the host): four LDS-DMA pieces per thread, all in
         // flight at once -- every one of the 32 400 workgroups of an 8K frame pays this prologue
         const int wave_e0 = __builtin_amdgcn_readfirstlane(tid & ~63);
-        if (weights_by_dma) {
+        if (SDMA || weights_by_dma) {
 #pragma unroll
             for (int i = 0; i < (C2N * 30 + 255) / 256; ++i) {
                 const int e = tid + i * 256;
@@ -941,6 +963,40 @@ __global__ __launch_bounds__(256) void k_conv3(
         hm[i] = rr / C3_LH;
         hoff[i] = ((offs_t)row_of(rr - hm[i] * C3_LH) * (offs_t)W + (offs_t)hx) * 4u;
     }
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    // SDMA halo: thread (row, hq) of the first 80 moves its 4 halo columns of one staged row, once per channel of the chunk
+    // (uniform plane base again); waves 2 and 3 skip it
+    float halo4[C3_MC];
+    const int h4row = min(tid >> 2, C3_LH - 1);
+    const unsigned h4off = ((unsigned)row_of(h4row) * (unsigned)W + (unsigned)hx) * 4u;
+    auto issue_dma = [&](int mc, float* dst) {     // SDMA: global -> LDS for the chunk starting at channel mc
+        if (tid < C3_LH * 4) {
+#pragma unroll
+            for (int m = 0; m < C3_MC; ++m)
+                halo4[m] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(C2 + (size_t)(mc + m) * plane_stride) + h4off);
+        }
+#pragma unroll
+        for (int m = 0; m < C3_MC; ++m) {
+            // the plane's base as an SGPR pair, whatever the halo loads above made of the same expression
+            const unsigned long long pb = reinterpret_cast<unsigned long long>(C2 + (size_t)(mc + m) * plane_stride);
+            const unsigned ub_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32));
+            const unsigned ub_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb);       // (the builtin returns int: no sign extension)
+            const unsigned long long ub = ((unsigned long long)ub_hi << 32) | (unsigned long long)ub_lo;
+#pragma unroll
+            for (int j = 0; j < C3_LH / 4; ++j) {
+                const int i = m * (C3_LH / 4) + j;
+                if constexpr (!OFF64)
+                    rs_dma_dword_s(reinterpret_cast<const void*>(ub), boff[j], dst + (wv_s + 4 * i) * C3_LW + 2);
+            }
+        }
+    };
+    auto land_dma = [&](float* dst) {              // SDMA: the halo registers -> LDS; every DMA of this wave has landed
+        if (tid < C3_LH * 4) {
+#pragma unroll
+            for (int m = 0; m < C3_MC; ++m) dst[m * C3_CH + h4row * C3_LW + hlc] = halo4[m];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     auto issue = [&](int mc) {                // global -> registers for chunk starting at channel mc
 #pragma unroll
         for (int i = 0; i < C3_BODY; ++i) {
@@ -968,15 +1024,25 @@ __global__ __launch_bounds__(256) void k_conv3(
 
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
-    land(tile[0]);
+    if constexpr (SDMA) { issue_dma(0, tile[0]); land_dma(tile[0]); }
+    else { issue(0); land(tile[0]); }
     if constexpr (STRICT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight image's DMA
     __syncthreads();
+
+    // SDMA: the lane's two LDS row bases (rows 0-3 and 4-7 of its 8-row window; every ds_read offset then fits the
+    // instruction's 8-bit dword field).  The second one is made opaque so that it stays a base instead of being folded into
+    // ten per-channel address additions.
+    const int offA = (wv * 4) * C3_LW + lane;
+    int offB = offA + 4 * C3_LW;
+    asm volatile("" : "+v"(offB));
 
 #pragma unroll 1
     for (int c = 0; c < C2N / C3_MC; ++c) {
         const float* cur = tile[c & 1];
-        if (c + 1 < C2N / C3_MC) issue((c + 1) * C3_MC);
+        if (c + 1 < C2N / C3_MC) {
+            if constexpr (SDMA) issue_dma((c + 1) * C3_MC, tile[(c + 1) & 1]);
+            else issue((c + 1) * C3_MC);
+        }
 #pragma unroll 1
         for (int m = 0; m < C3_MC; ++m) {
             const float* t = cur + m * C3_CH + (wv * 4) * C3_LW + lane;
@@ -995,6 +1061,47 @@ __global__ __launch_bounds__(256) void k_conv3(
 #pragma unroll
                             for (int dx = 0; dx < 5; ++dx) a[q] = __builtin_fma(wd[dy * 5 + dx], v[dx], a[q]);
                         }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum[q] = (float)((double)sum[q] + a[q]);
+            } else if constexpr (STRICT && SDMA) {
+                // As the branch below, with the window rows addressed from two fixed bases and the fifth window column
+                // read as the (row k, row k+1) pairs its packed products consume -- pixels (q, q+1) share a weight there.
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const float* tA = cur + m * C3_CH + offA;
+                const float* tB = cur + m * C3_CH + offB;
+                f2 va[8], vb[8], vp[7];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    va[r] = f2{tA[r * C3_LW + 0], tA[r * C3_LW + 1]};
+                    vb[r] = f2{tA[r * C3_LW + 2], tA[r * C3_LW + 3]};
+                    va[r + 4] = f2{tB[r * C3_LW + 0], tB[r * C3_LW + 1]};
+                    vb[r + 4] = f2{tB[r * C3_LW + 2], tB[r * C3_LW + 3]};
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    vp[k] = f2{tA[k * C3_LW + 4], tA[(k + 1) * C3_LW + 4]};
+                    vp[k + 4] = f2{tB[k * C3_LW + 4], tB[(k + 1) * C3_LW + 4]};
+                }
+                vp[3] = f2{tA[3 * C3_LW + 4], tB[4]};
+                const float* wrow = w3s + (c * C3_MC + m) * 30;
+                double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy) {
+                    const f2 wa = f2{wrow[dy * 6 + 0], wrow[dy * 6 + 1]};
+                    const f2 wb = f2{wrow[dy * 6 + 2], wrow[dy * 6 + 3]};
+                    const f2 wc = f2{wrow[dy * 6 + 4], wrow[dy * 6 + 4]};
+                    const f2 pc01 = wc * vp[dy], pc23 = wc * vp[dy + 2];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f2 pa = wa * va[q + dy], pb = wb * vb[q + dy];
+                        const float pc = q == 0 ? pc01.x : q == 1 ? pc01.y : q == 2 ? pc23.x : pc23.y;
+                        a[q] = (dy == 0) ? (double)pa.x : a[q] + (double)pa.x;
+                        a[q] = a[q] + (double)pa.y;
+                        a[q] = a[q] + (double)pb.x;
+                        a[q] = a[q] + (double)pb.y;
+                        a[q] = a[q] + (double)pc;
                     }
                 }
 #pragma unroll
@@ -1059,7 +1166,10 @@ __global__ __launch_bounds__(256) void k_conv3(
                 }
             }
         }
-        if (c + 1 < C2N / C3_MC) land(tile[(c + 1) & 1]);
+        if (c + 1 < C2N / C3_MC) {
+            if constexpr (SDMA) land_dma(tile[(c + 1) & 1]);
+            else land(tile[(c + 1) & 1]);
+        }
         __syncthreads();
     }
     const int x = tx0 + lane;
@@ -1478,7 +1588,10 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
     const bool force_wide = settings().conv3_off64;      // test hook
     const int wdma = settings().conv3_wdma ? 1 : 0;
     const bool wide = force_wide || (size_t)c2_rows * (size_t)W * sizeof(float) >= ((size_t)1 << 32);     // per-plane byte offsets beyond 32 bits
-    if (!wide)
+    if (!wide && wdma)
+        hipLaunchKernelGGL((k_conv3<true, false, false, true>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
+                           out, out_row0, out_rows, 1);
+    else if (!wide)
         hipLaunchKernelGGL((k_conv3<true, false>), grid, dim3(256), 0, s, C2, plane_stride, W, H, c2_row_base, c2_rows,
                            out, out_row0, out_rows, wdma);
     else
