@@ -8,16 +8,29 @@
 #   make test       -> CPU test-suite;  make gpu-test on a gfx950 box
 #   make ubench     -> tools/ubench/bin/* (microbenchmarks; hipcc, gfx950)
 #   make asan tsan  -> the host code (table builder, drop-in control flow, oracle) under ASan+UBSan / TSan, CPU only
+#   make STRICT_ONLY=1 -> the same artefacts under libsrcnn_amd/lib/strict/ with NO non-parity kernel compiled in (no FAST /
+#                      FAST_F16 / RELAXED template instance, no srcnn_fused_f16.hip); srcnn_set_mode refuses those modes
 HIPCC   ?= /opt/rocm/bin/hipcc
 CSRC    := libsrcnn_amd/csrc
+ifeq ($(STRICT_ONLY),1)
+LIBDIR  := libsrcnn_amd/lib/strict
+BINDIR  := libsrcnn_amd/lib/strict/bin
+STRICT_DEF := -DSRCNN_STRICT_ONLY
+else
 LIBDIR  := libsrcnn_amd/lib
 BINDIR  := libsrcnn_amd/bin
+STRICT_DEF :=
+endif
 # -ffp-contract=off: the strict kernels and the host table builder must round every multiply and add separately
 HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fvisibility=hidden -Wall \
-            -Wno-unused-result -Wno-unused-value -Wno-ignored-attributes -D__HIP_PLATFORM_AMD__
+            -Wno-unused-result -Wno-unused-value -Wno-ignored-attributes -D__HIP_PLATFORM_AMD__ $(STRICT_DEF)
+ifeq ($(STRICT_ONLY),1)
+SRCS    := srcnn_kernels.hip srcnn_capi.cpp srcnn_pipeline.cpp srcnn_comm.cpp dropin.cpp
+else
 SRCS    := srcnn_kernels.hip srcnn_fused_f16.hip srcnn_capi.cpp srcnn_pipeline.cpp srcnn_comm.cpp dropin.cpp
+endif
 OBJS    := $(addprefix $(LIBDIR)/,$(addsuffix .o,$(basename $(SRCS))))
-HDRS    := $(CSRC)/srcnn_kernels.h $(CSRC)/srcnn_host.hpp $(CSRC)/srcnn_settings.hpp $(CSRC)/srcnn_watchdog.hpp $(CSRC)/resample_table.hpp $(CSRC)/srcnn_weights.inc include/srcnn_amd.h include/libsrcnn_dropin.h
+HDRS    := $(CSRC)/srcnn_kernels.h $(CSRC)/srcnn_host.hpp $(CSRC)/srcnn_settings.hpp $(CSRC)/srcnn_watchdog.hpp $(CSRC)/resample_table.hpp $(CSRC)/srcnn_weights.inc include/srcnn_amd.h include/srcnn_amd_debug.h include/libsrcnn_dropin.h
 
 PREFIX  ?= /usr/local
 ROCM    ?= /opt/rocm
@@ -75,7 +88,7 @@ gpu-test: all oracle
 
 # CPU-only sanitizer builds of the host code (no GPU sanitizer exists on this pool): tests/host/host_sanitize.cpp
 SAN_SRCS := tests/host/host_sanitize.cpp $(CSRC)/dropin.cpp
-SAN_DEPS := $(SAN_SRCS) $(CSRC)/resample_table.hpp $(CSRC)/srcnn_watchdog.hpp oracle/srcnn_oracle.c include/srcnn_amd.h include/libsrcnn_dropin.h
+SAN_DEPS := $(SAN_SRCS) $(CSRC)/resample_table.hpp $(CSRC)/srcnn_watchdog.hpp oracle/srcnn_oracle.c include/srcnn_amd.h include/srcnn_amd_debug.h include/libsrcnn_dropin.h
 tests/host/_build/oracle_%.o: oracle/srcnn_oracle.c oracle/oracle_weights.inc
 	@mkdir -p tests/host/_build
 	gcc -O1 -g -ffp-contract=off -std=c99 -fsanitize=$(subst asan,address$(comma)undefined,$(subst tsan,thread,$*)) -fno-omit-frame-pointer -c $< -o $@

@@ -167,6 +167,16 @@ def process_srcnn_wall(S):
         out[name] = {"best_ms": round(min(ts) * 1e3, 2), "median_ms": round(sorted(ts)[len(ts) // 2] * 1e3, 2),
                      "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
                      "host_cpu_ms_per_call": round(sorted(cs)[len(cs) // 2] * 1e3, 2)}
+        ph = (C.c_double * 8)()
+        if L.srcnn_debug_process_phases(ph, 8) >= 6 and h >= 2160:
+            # where the LAST call's time went (include/srcnn_amd_debug.h): milliseconds since the call's work began
+            out[name]["phases_ms_last_call"] = {
+                "call_ms": round(ts[-1] * 1e3, 2), "setup_done": round(ph[0], 2), "first_band_queued": round(ph[1], 2),
+                "last_kernels_done": round(ph[2], 2), "last_band_landed": round(ph[3], 2), "fanned_out": round(ph[4], 2),
+                "bands": int(ph[5]),
+                "note": "device busy from first_band_queued to last_kernels_done; before it: lane lease, tables, the first band's "
+                        "stage-in (memcpy into page-locked staging + H2D); after it: the last band's D2H and its copy into the "
+                        "caller's fresh new[] block"}
     # The same image through the C ABI's srcnn_process_u8 into a caller-owned, REUSED result buffer: what a caller that
     # upscales a sequence should use -- no fresh 100 MB of pages per call (tools/concurrent_probe.py has the multi-caller runs).
     h, w = 2160, 3840
@@ -269,6 +279,146 @@ def pcie_inclusive(S, frames=16):
                     "`plain_launches` = the same stream without graphs.  host_cpu_s_per_frame = process CPU time (all "
                     "threads) per frame: the library's threads sleep or poll; with graph replay a thread of the ROCm "
                     "runtime stays busy from launch to completion (tools/runtime_thread_probe.py).  Never the headline value"}
+
+
+_CONFIG2_CHILD = r"""
+import json, sys, time
+t_start = time.perf_counter()
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import libsrcnn_amd as S
+from libsrcnn_amd import synth
+t0 = time.perf_counter(); S.init(0); init_ms = (time.perf_counter() - t0) * 1e3
+L = S.lib()
+w, h = 1920, 1080
+y = synth.plane(h, w, synth.SEED0, "smooth")
+# (a) what a caller with host memory sees: pageable float32 in -> pageable float32 out, blocking
+t0 = time.perf_counter(); out = S.y_upscale2x(y); cold_host = (time.perf_counter() - t0) * 1e3
+warm_host = []
+for _ in range(15):
+    t0 = time.perf_counter(); out = S.y_upscale2x(y); warm_host.append((time.perf_counter() - t0) * 1e3)
+# (b) resident: device pointer in -> device pointer out, call + device sync
+d_in = S.DeviceBuffer.from_numpy(y); d_out = S.DeviceBuffer(4 * w * h * 4)
+S.sync()
+warm_dev = []
+for _ in range(30):
+    t0 = time.perf_counter(); S.check(L.srcnn_y_upscale2x_f32_dev(d_in.ptr, w, h, d_out.ptr, None)); S.sync()
+    warm_dev.append((time.perf_counter() - t0) * 1e3)
+warm_host.sort(); warm_dev.sort()
+print(json.dumps({"init_ms": init_ms, "cold_first_call_host_ms": cold_host, "warm_host_median_ms": warm_host[len(warm_host) // 2],
+                  "warm_host_min_ms": warm_host[0], "warm_resident_median_ms": warm_dev[len(warm_dev) // 2],
+                  "warm_resident_min_ms": warm_dev[0], "process_start_to_first_result_ms": None}))
+"""
+
+
+def baseline_configs(S):
+    """BASELINE.json configs #2, #3 and #4 on this one GPU, each with the reference's own yardstick -- the wall time of the
+    call (src/test.cpp:653-672) -- outside the contract's timed region.
+    #2 runs in a fresh child process, so that `cold_first_call` really is the first call of a process (context, streams,
+    scratch, the resample table); #3 and #4 run here.  #4 goes through the RCCL entry point at world 1."""
+    import ctypes as C
+    from libsrcnn_amd import synth, multigpu
+    L = S.lib()
+    out = {}
+    r = subprocess.run([sys.executable, "-c", _CONFIG2_CHILD, ROOT], capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        c2 = json.loads(r.stdout.strip().splitlines()[-1])
+        n = 4 * 1920 * 1080 / 1e6
+        out["2_single_1080p_frame"] = {
+            "shape": "1920x1080 -> 3840x2160 Y, strict",
+            "cold_first_call_ms": round(c2["cold_first_call_host_ms"], 2),
+            "device_init_ms": round(c2["init_ms"], 1),
+            "warm_median_ms": round(c2["warm_host_median_ms"], 3), "warm_min_ms": round(c2["warm_host_min_ms"], 3),
+            "warm_resident_median_ms": round(c2["warm_resident_median_ms"], 3),
+            "warm_resident_min_ms": round(c2["warm_resident_min_ms"], 3),
+            "MPix/s_warm_resident": round(n / (c2["warm_resident_median_ms"] * 1e-3), 1),
+            "note": "fresh process; cold_first_call / warm_median: srcnn_y_upscale2x_f32 on pageable host float32 in and out "
+                    "(H2D + path + D2H, blocking); warm_resident: device pointers, call + device sync; device_init = srcnn_init"}
+    else:
+        out["2_single_1080p_frame"] = {"error": r.stderr[-300:]}
+    # #3: batch of 64 resident 1080p frames, one call per step
+    w, h, F = 1920, 1080, 64
+    d_in = S.DeviceBuffer(F * w * h * 4)
+    d_out = S.DeviceBuffer(F * 4 * w * h * 4)
+    two = synth.frames(2, h, w, 0, "smooth")
+    for f in range(F):
+        d_in.upload(two[f & 1], offset=f * w * h * 4)
+
+    def step3():
+        S.check(L.srcnn_y_upscale2x_f32_batch_dev(d_in.ptr, w, h, F, d_out.ptr, None))
+    step3(); S.sync()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); step3(); S.sync(); ts.append(time.perf_counter() - t0)
+    out["3_batch_64x1080p"] = {"shape": "64 x (1920x1080 -> 3840x2160) resident, one call", "ms_per_batch": round(min(ts) * 1e3, 2),
+                               "MPix/s": round(F * 4 * w * h / 1e6 / min(ts), 1), "best_of": 3}
+    del d_in, d_out
+    # #4: one 7680x4320 frame -> 15360x8640 through the multi-GPU entry point (RCCL communicator of ONE rank here: the band
+    # plan, the piece loop and the comm stream run; ncclSend/ncclRecv have no peer to talk to)
+    try:
+        w, h = 7680, 4320
+        d_in = S.DeviceBuffer.from_numpy(synth.plane(h, w, synth.SEED0, "smooth"))
+        multigpu.init_comm_from_torch_dist(None, 0, 1)
+        tiled = multigpu.TiledFrameGPU(w, h, 0, 1, nsub=4)
+
+        def step4():
+            tiled.step(d_in)
+            S.check(L.srcnn_comm_wait(None))
+            S.sync()
+        step4()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); step4(); ts.append(time.perf_counter() - t0)
+        out["4_tiled_8k_frame_world1"] = {"shape": "7680x4320 -> 15360x8640 via srcnn_comm_tiled_y_upscale2x_f32_dev, world 1, 4 pieces",
+                                          "ms_per_frame": round(min(ts) * 1e3, 2), "MPix/s": round(4 * w * h / 1e6 / min(ts), 1),
+                                          "best_of": 3}
+        del tiled, d_in
+        L.srcnn_comm_destroy()
+    except Exception as e:                                        # noqa: BLE001
+        out["4_tiled_8k_frame_world1"] = {"error": repr(e)}
+    return out
+
+
+def roofline_all(stage_ms, n_out, in_px):
+    """Every kernel of the strict path against ITS OWN bound: achieved, the peak or floor it is held to,
+    and the fraction.  stage_ms = average launch duration per 4K -> 8K frame from the HIP events of the timed region."""
+    CLK = 2.4e9
+    SIMDS = 256 * 4
+    rows = []
+    if stage_ms.get("conv12"):
+        ms = stage_ms["conv12"]
+        tf = 2.0 * MAC_L12 * n_out / (ms * 1e-3) / 1e12
+        # strict tap-step floor measured by tools/ubench/occupancy_tapstep.hip: 70 cycles per 1024 MAC and SIMD
+        floor_ms = (MAC_L12 * n_out / 1024.0) * 70.0 / SIMDS / CLK * 1e3
+        rows.append({"kernel": "k_conv12_mfma", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_F32_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+                     "own_floor": {"what": "no-FMA ceiling (product and sum rounded separately): 0.5 of peak; measured floor of the "
+                                           "MFMA-product + VALU-sum step: 70 cycles per 1024 MAC per SIMD at 2.4 GHz "
+                                           "(profiles/r06_occupancy_tapstep.txt)",
+                                   "frac_of_no_fma_ceiling": round(tf / (PEAK_F32_TFLOPS / 2), 4),
+                                   "floor_ms": round(floor_ms, 3), "frac_of_floor": round(floor_ms / ms, 4)}})
+    if stage_ms.get("conv3"):
+        ms = stage_ms["conv3"]
+        tf = 2.0 * 800 * n_out / (ms * 1e-3) / 1e12
+        # per wave (64 lanes x 4 pixels) and channel: 50 v_pk_mul_f32 + 104 v_cvt_f64_f32 + 100 v_add_f64 = 254 instructions at the
+        # 4.14 cycles per instruction of the same mix in a register-only stream (profiles/r03_valu_rates.txt, "conv3 pair")
+        floor_ms = (n_out / 256.0) * 32 * 254 * 4.14 / SIMDS / CLK * 1e3
+        rows.append({"kernel": "k_conv3", "bound": "valu", "achieved": round(tf, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_F32_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+                     "own_floor": {"what": "fp64-rate VALU issue: per MAC one half v_pk_mul_f32, one v_cvt_f64_f32 and one v_add_f64 "
+                                           "(the reference rounds the product to fp32, then sums in fp64); 254 instructions per wave "
+                                           "and channel at the mix's measured 4.14 cycles each (profiles/r03_valu_rates.txt), 2.4 GHz",
+                                   "floor_ms": round(floor_ms, 3), "frac_of_floor": round(floor_ms / ms, 4)}})
+    if stage_ms.get("resample"):
+        ms = stage_ms["resample"]
+        nbytes = 4.0 * in_px + 4.0 * n_out
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append({"kernel": "k_rs2d_dma", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(ms, 4),
+                     "own_floor": {"what": "algorithmic bytes: fp32 source plane in + fp32 2x plane out", "bytes_per_launch": nbytes,
+                                   "floor_ms": round(nbytes / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
+                                   "frac_of_floor": round(nbytes / (PEAK_HBM_GBS * 1e9) * 1e3 / ms, 4)}})
+    return rows
 
 
 _RESULT_FD = None
@@ -818,6 +968,7 @@ def main():
                                  "achieved_GBps": round(alg_bytes12 / (avg12 * 1e-3) / 1e9, 1) if avg12 > 0 else 0.0,
                                  "peak_GBps": PEAK_HBM_GBS,
                                  "frac": round(alg_bytes12 / (avg12 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if avg12 > 0 else 0.0}},
+            "roofline_all": roofline_all(stage, n_out, n_in),
             "stage_avg_ms_per_frame": stage,
             "whole_path": {"tflops": round(2.0 * MAC_ALL * mpix_step * 1e6 / (ms_per_step * 1e-3) / 1e12, 3),
                            "hbm_algorithmic_GBps": round(5 * mpix_step * 1e6 / (ms_per_step * 1e-3) / 1e9, 2),
@@ -875,6 +1026,10 @@ def main():
                 out["process_srcnn_ms"] = process_srcnn_wall(S)
             except Exception as e:                                # noqa: BLE001
                 out["extras_error"] = repr(e)
+            try:
+                out["configs"] = baseline_configs(S)
+            except Exception as e:                                # noqa: BLE001
+                out["configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and args.tier == "strict":
             try:
                 out["cpu_baseline"], out["max_abs_dY_vs_cpu_ref"] = cpu_baseline(S)

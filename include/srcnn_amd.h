@@ -35,10 +35,15 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define SRCNN_AMD_ABI_VERSION 5   /* 2: srcnn_comm_gatherv_f32, srcnn_comm_rank, srcnn_debug_counts
+#define SRCNN_AMD_ABI_VERSION 5   /* FROZEN at 5 since round 6.  This header is the STABLE ABI: the functions it declares are
+                                   * listed in include/srcnn_amd.abi (one name per line), tests/test_abi.py fails when the two or the
+                                   * library's export table disagree, so an addition is a deliberate edit of that list and a bump here.
+                                   * Instruments (test hooks, diagnostics, the relaxation experiment) live in srcnn_amd_debug.h
+                                   * and carry no compatibility promise.
+                                   * 2: srcnn_comm_gatherv_f32, srcnn_comm_rank
                                    * 3: contexts (srcnn_init_devices ...), node-level calls, srcnn_trim, sub-band gather
-                                   * 4: SRCNN_MODE_RELAXED / srcnn_set_relaxation, srcnn_process_u8_begin/_wait, srcnn_comm_wait / srcnn_comm_set_timeout_ms
-                                   * 5: srcnn_debug_settings; gather tables verified across the ranks by default */
+                                   * 4: srcnn_process_u8_begin/_wait, srcnn_comm_wait / srcnn_comm_set_timeout_ms
+                                   * 5: gather tables verified across the ranks by default */
 
 /* error codes.  -1/-2/-11/-12/-100 are the reference's own (src/libsrcnn.cpp:951-966,883,910,636) */
 #define SRCNN_OK            0
@@ -64,16 +69,6 @@ extern "C" {
 #define SRCNN_MODE_FAST     1   /* fp32 FMA chains (layers 1+2 on the fp32 MFMA, layer 3 v_fma_f32) */
 #define SRCNN_MODE_FAST_F16 2   /* layers 1+2 as split-fp16 GEMMs on the fp16 matrix pipe (3 MFMAs per product
                                  * term set, fp32 accumulate); same error class as SRCNN_MODE_FAST */
-#define SRCNN_MODE_RELAXED  3   /* the strict kernels with the roundings named by srcnn_set_relaxation() given up, layer by
-                                 * layer: the instrument behind the per-layer error matrix (profiles/r04_error_matrix.txt).
-                                 * NOT a parity tier: every single relaxation measures above the 1e-4 bar */
-/* relaxation bits (src/libsrcnn.cpp:395-410 layer 1, :433-437 layer 2, :500-517 layer 3) */
-#define SRCNN_RELAX_L1      1u  /* layer 1: acc = fma(w, y, acc) per tap (fp32 MFMA, C = acc) instead of product then add */
-#define SRCNN_RELAX_L2      2u  /* layer 2: likewise over the 64 channels */
-#define SRCNN_RELAX_L3_X64  4u  /* layer 3: exact products (v_fma_f64 on widened operands) instead of fp32-rounded ones;
-                                 * per-channel fp64 sums and the fp32 running sum as the reference's */
-#define SRCNN_RELAX_L3_F32  8u  /* layer 3: fp32 FMA chain per channel */
-
 /* ---- lifecycle (the reference has none: it is stateless CPU code; src/libsrcnn.cpp:91-92 are its
  *      only globals).  srcnn_init is idempotent and thread-safe; every compute call self-inits on
  *      device 0 if it was never called.
@@ -85,7 +80,8 @@ extern "C" {
  *   - *_dev calls take their scratch from the given stream's workspace; two threads using the SAME stream are
  *     serialised while they enqueue, different streams are independent.
  *   - The numerics mode is sampled once when a call starts (for the asynchronous pair: in srcnn_process_u8_begin); srcnn_set_mode
- *     never affects a call in flight.
+ *     never affects a call in flight.  A strict-only build of the library (make STRICT_ONLY=1) refuses every mode but
+ *     SRCNN_MODE_STRICT with SRCNN_E_UNSUPPORTED.
  *   - srcnn_stream_destroy / srcnn_batch_graph_destroy / srcnn_shutdown must not race with calls that still use
  *     that stream / graph / the library (as with any handle).
  *
@@ -114,8 +110,6 @@ int         srcnn_trim(void);                      /* give back what idle lanes 
 const char* srcnn_last_error(void);
 int         srcnn_set_mode(int mode);              /* SRCNN_MODE_*; returns previous mode or <0 */
 int         srcnn_get_mode(void);
-int         srcnn_set_relaxation(unsigned mask);   /* SRCNN_RELAX_* bits used by SRCNN_MODE_RELAXED (default L3_X64);
-                                                    * returns the previous mask or <0.  Takes effect for calls that start later */
 int         srcnn_device_name(char* buf, size_t cap);
 /* Upper bound, in bytes, on the layer-2 scratch (128 B per output pixel) one pass may hold; larger frames / bands
  * are produced in horizontal sub-bands with identical results.  Default 16 GiB or env SRCNN_MAX_WORKSPACE_MB.
@@ -259,36 +253,6 @@ int srcnn_output_size(unsigned w, unsigned h, float multiply, int stepscale, uns
 /* delete[] for buffers handed out by ProcessSRCNN (outbuff / *convbuff), for callers that cannot
  * run C++ delete[] themselves (ctypes, cgo, JNI ...).  The reference leaves this to the caller. */
 void srcnn_delete_array(unsigned char* p);
-
-/* The table FRawScaleWeightsTable builds (src/frawscale.cpp:8-112), exposed for tests:
- * returns the window size; if left/right/weights are non-NULL fills dst_len entries
- * (weights row stride = window+1 doubles). */
-int srcnn_axis_table(int filter, unsigned dst_len, unsigned src_len, int* left, int* right, double* weights);
-
-/* Diagnostic: the fused non-parity kernel alone on an already upscaled plane (w x h), optionally with in-kernel
- * s_memtime stamps of workgroup 0 (d_dbg: 8 x 64 x 4 uint64, or NULL).  Used by tools/fused_timeline.py. */
-int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, unsigned long long* d_dbg, void* stream);
-
-/* Test hook: number of contribution tables currently cached (bounded, only unreferenced tables are evicted) and
- * of ProcessSRCNN lanes created so far (at most 4 per context), both summed over the contexts. */
-int srcnn_debug_counts(int* tables, int* lanes);
-
-/* Every SRCNN_* environment switch of the library is read ONCE, when the library is loaded, into one table
- * (libsrcnn_amd/csrc/srcnn_settings.hpp): this prints what the process runs with, one "NAME=value (default D)  -- effect" line
- * per switch (markdown != 0: the table rows of DESIGN.md section 6).  The text is written to buf (NUL-terminated, truncated to
- * cap; buf may be NULL); the return value is the length the whole text needs.  No device needed. */
-int srcnn_debug_settings(char* buf, size_t cap, int markdown);
-
-/* Diagnostic: the shader clock of every layer-1+2 launch.  While on, each launch records the shader-cycle and 100 MHz counters
- * over the lifetime of its first workgroup (cycles / ticks x 100 = MHz; ticks / 100 = microseconds).  probe(on) resets the
- * record and returns the previous setting; read() synchronises the device, returns the number of launches recorded on
- * `context` (at most 8192 are kept) and writes up to `cap` of them in launch order. */
-int srcnn_debug_clock_probe(int on);
-int srcnn_debug_clock_read(int context, unsigned long long* cycles, unsigned long long* ticks, int cap);
-
-/* Test hook (no device needed): the band cut points srcnn_process_u8 uses for output rows [r0, r1) of a dw-wide image under
- * the current workspace limit; returns their number (first = r0, last = r1), writes at most `cap` of them. */
-int srcnn_debug_band_plan(unsigned r0, unsigned r1, unsigned dw, int one_of_many, unsigned* cuts, int cap);
 
 /* ---- multi-GPU, one process per GPU: RCCL over xGMI only for the band gather.  The communicator binds to the calling
  * thread's current context (its device).

@@ -21,30 +21,33 @@ SRCNNF_Nearest, SRCNNF_Bilinear, SRCNNF_Bicubic, SRCNNF_Lanczos3, SRCNNF_Bspline
 MODE_STRICT, MODE_FAST, MODE_FAST_F16, MODE_RELAXED = 0, 1, 2, 3
 RELAX_L1, RELAX_L2, RELAX_L3_X64, RELAX_L3_F32 = 1, 2, 4, 8
 
-# every symbol include/srcnn_amd.h declares (checked by tests/test_abi.py)
-C_ABI_SYMBOLS = [
+# The STABLE C ABI: every function include/srcnn_amd.h declares, frozen at ABI 5 (include/srcnn_amd.abi is the committed list;
+# tests/test_abi.py holds header, list, this binding and the library's export table to each other)
+STABLE_ABI_SYMBOLS = [
     "srcnn_abi_version", "srcnn_device_count", "srcnn_init", "srcnn_init_devices", "srcnn_context_count",
-    "srcnn_context_device", "srcnn_set_context", "srcnn_get_context", "srcnn_shutdown", "srcnn_trim", "srcnn_last_error",
-    "srcnn_set_mode", "srcnn_get_mode", "srcnn_set_relaxation", "srcnn_device_name", "srcnn_set_workspace_limit",
-    "srcnn_dev_alloc", "srcnn_dev_free", "srcnn_host_alloc_pinned", "srcnn_host_free_pinned",
-    "srcnn_memcpy_h2d", "srcnn_memcpy_d2h", "srcnn_memset_dev", "srcnn_stream_create", "srcnn_stream_destroy",
-    "srcnn_stream_sync", "srcnn_device_sync", "srcnn_event_create", "srcnn_event_destroy", "srcnn_event_record",
-    "srcnn_stream_wait_event",
-    "srcnn_event_elapsed_ms",
-    "srcnn_profile_enable", "srcnn_profile_reset", "srcnn_profile_read", "srcnn_profile_read_context",
-    "srcnn_y_upscale2x_f32_dev", "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev",
-    "srcnn_y_upscale2x_f32_node_dev",
-    "srcnn_batch_graph_create", "srcnn_batch_graph_launch", "srcnn_batch_graph_destroy",
-    "srcnn_y_path_f32_dev", "srcnn_resample_f32_dev", "srcnn_conv1_f32_dev", "srcnn_conv2_f32_dev",
-    "srcnn_conv3_f32_dev", "srcnn_conv12_f32_dev",
-    "srcnn_y_upscale2x_f32", "srcnn_y_upscale2x_f32_batch", "srcnn_y_upscale2x_f32_stream", "srcnn_y_path_f32",
-    "srcnn_process_u8", "srcnn_process_u8_begin", "srcnn_process_u8_wait",
-    "srcnn_delete_array", "srcnn_output_size", "srcnn_axis_table",
-    "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_rank", "srcnn_comm_gather_f32",
-    "srcnn_comm_gatherv_f32", "srcnn_comm_gatherv_at_f32", "srcnn_comm_tiled_y_upscale2x_f32_dev", "srcnn_band_rows", "srcnn_tiled_piece", "srcnn_debug_band_plan",
-    "srcnn_comm_allgather_f32", "srcnn_comm_barrier", "srcnn_comm_wait", "srcnn_comm_set_timeout_ms", "srcnn_debug_counts", "srcnn_fused_diag",
-    "srcnn_debug_clock_probe", "srcnn_debug_clock_read", "srcnn_debug_settings",
+    "srcnn_context_device", "srcnn_set_context", "srcnn_get_context", "srcnn_shutdown", "srcnn_trim",
+    "srcnn_last_error", "srcnn_set_mode", "srcnn_get_mode", "srcnn_device_name", "srcnn_set_workspace_limit",
+    "srcnn_dev_alloc", "srcnn_dev_free", "srcnn_host_alloc_pinned", "srcnn_host_free_pinned", "srcnn_memcpy_h2d",
+    "srcnn_memcpy_d2h", "srcnn_memset_dev", "srcnn_stream_create", "srcnn_stream_destroy", "srcnn_stream_sync",
+    "srcnn_device_sync", "srcnn_event_create", "srcnn_event_destroy", "srcnn_event_record",
+    "srcnn_stream_wait_event", "srcnn_event_elapsed_ms", "srcnn_profile_enable", "srcnn_profile_reset",
+    "srcnn_profile_read", "srcnn_profile_read_context", "srcnn_y_upscale2x_f32_dev",
+    "srcnn_y_upscale2x_f32_batch_dev", "srcnn_y_upscale2x_f32_band_dev", "srcnn_y_upscale2x_f32_node_dev",
+    "srcnn_batch_graph_create", "srcnn_batch_graph_launch", "srcnn_batch_graph_destroy", "srcnn_y_path_f32_dev",
+    "srcnn_resample_f32_dev", "srcnn_conv1_f32_dev", "srcnn_conv2_f32_dev", "srcnn_conv3_f32_dev",
+    "srcnn_conv12_f32_dev", "srcnn_y_upscale2x_f32", "srcnn_y_upscale2x_f32_batch", "srcnn_y_upscale2x_f32_stream",
+    "srcnn_y_path_f32", "srcnn_process_u8", "srcnn_process_u8_begin", "srcnn_process_u8_wait", "srcnn_delete_array",
+    "srcnn_output_size", "srcnn_comm_unique_id", "srcnn_comm_init", "srcnn_comm_destroy", "srcnn_comm_rank",
+    "srcnn_comm_gather_f32", "srcnn_comm_gatherv_f32", "srcnn_comm_gatherv_at_f32",
+    "srcnn_comm_tiled_y_upscale2x_f32_dev", "srcnn_band_rows", "srcnn_tiled_piece", "srcnn_comm_allgather_f32",
+    "srcnn_comm_barrier", "srcnn_comm_wait", "srcnn_comm_set_timeout_ms",
 ]
+# instruments (include/srcnn_amd_debug.h): test hooks, diagnostics, the relaxation experiment -- no compatibility promise
+DEBUG_SYMBOLS = [
+    "srcnn_set_relaxation", "srcnn_axis_table", "srcnn_fused_diag", "srcnn_debug_counts", "srcnn_debug_settings",
+    "srcnn_debug_clock_probe", "srcnn_debug_clock_read", "srcnn_debug_band_plan", "srcnn_debug_process_phases",
+]
+C_ABI_SYMBOLS = STABLE_ABI_SYMBOLS + DEBUG_SYMBOLS          # everything the library exports besides the two C++ symbols
 CXX_SYMBOLS = ["_Z20ConfigureFilterSRCNN15SRCNNFilterTypeb", "_Z12ProcessSRCNNPKhjjjfRPhRjPS1_Pj"]
 
 

@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libsrcnn_amd.so")
 
 SOURCES = ["srcnn_kernels.hip", "srcnn_fused_f16.hip", "srcnn_capi.cpp", "srcnn_pipeline.cpp", "srcnn_comm.cpp", "dropin.cpp"]
 DEPS = SOURCES + ["../../tools/srcnntest.cpp", "srcnn_kernels.h", "srcnn_host.hpp", "srcnn_settings.hpp", "srcnn_watchdog.hpp", "resample_table.hpp", "srcnn_weights.inc",
-                  "../../include/srcnn_amd.h", "../../include/libsrcnn_dropin.h", "exports.map"]
+                  "../../include/srcnn_amd.h", "../../include/srcnn_amd_debug.h", "../../include/libsrcnn_dropin.h", "exports.map"]
 
 # -ffp-contract=off: strict kernels and the host table builder must round every multiply and add
 # separately (the reference binary contains no FMA).  FAST kernels call fmaf explicitly.
@@ -104,6 +104,42 @@ def kernel_source_sha(name="k_conv12_mfma"):
     return h.hexdigest()
 
 
+STRICT_DIR = os.path.join(LIBDIR, "strict")
+STRICT_LIB = os.path.join(STRICT_DIR, "libsrcnn_amd.so")
+
+
+def build_strict_only(force=False, verbose=True):
+    """The strict-only product (`make STRICT_ONLY=1`): -DSRCNN_STRICT_ONLY, no srcnn_fused_f16.hip -- not one instance of a
+    non-parity kernel (FAST, FAST_F16, RELAXED) is compiled, srcnn_set_mode refuses every mode but SRCNN_MODE_STRICT with
+    SRCNN_E_UNSUPPORTED, and the exported symbol set is the full library's.  Lands in libsrcnn_amd/lib/strict/ (load it with
+    SRCNN_AMD_LIB=...).  Returns (path, seconds spent compiling or None if it was up to date)."""
+    import time
+    stamp = os.path.join(STRICT_DIR, "build.sha256")
+    digest = source_digest() + "-strict"
+    if not force and os.path.exists(STRICT_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return STRICT_LIB, None
+    os.makedirs(STRICT_DIR, exist_ok=True)
+    t0 = time.time()
+    objs = []
+    for src in SOURCES:
+        if src == "srcnn_fused_f16.hip":
+            continue
+        obj = os.path.join(STRICT_DIR, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc()] + FLAGS + ["-DSRCNN_STRICT_ONLY"] + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", STRICT_LIB, "-ldl", "-Wl,-soname,libsrcnn_amd.so",
+                                                                          "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
+    return STRICT_LIB, time.time() - t0
+
+
 def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
@@ -150,5 +186,9 @@ def build_cli(verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--strict-only" in sys.argv:
+        lib, secs = build_strict_only(force="--force" in sys.argv)
+        print(lib, "(%.0f s, %d bytes)" % (secs, os.path.getsize(lib)) if secs is not None else "(up to date, %d bytes)" % os.path.getsize(lib))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

@@ -180,7 +180,7 @@ void split_f16_bits(float v, unsigned short& hi, unsigned short& lo)
     memcpy(&lo, &l, 2);
 }
 
-void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
+[[maybe_unused]] void build_fused_f16_weights(const DevWeights& d, FusedF16Weights& f)
 {
     memset(&f, 0, sizeof f);
     for (int s = 0; s < FU_NK; ++s)
@@ -256,6 +256,7 @@ int make_context_locked(int device)
     build_dev_weights(*dw);
     HIP_TRY(upload_weights(*dw));
     HIP_TRY(conv12_mfma_prepare());
+#ifndef SRCNN_STRICT_ONLY
     auto fw = std::make_unique<FusedF16Weights>();
     build_fused_f16_weights(*dw, *fw);
     HIP_TRY(hipMalloc((void**)&cx->fused_w, sizeof(FusedF16Weights)));
@@ -267,6 +268,9 @@ int make_context_locked(int device)
     HIP_TRY(fused_f16_prepare());
     HIP_TRY(rs2d_prepare());
     guard.cx = nullptr;
+#else
+    HIP_TRY(rs2d_prepare());
+#endif
     cx->num_cus = prop.multiProcessorCount;
     cx->numa_node = device_numa_node(device);
     // direct copies between the devices of a node (the node-level tiled frame moves its bands with hipMemcpyPeerAsync)
@@ -789,13 +793,14 @@ int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw
     if (dh > (1u << 20) || h > (1u << 20) || dw > 0x7fffffu || (r1 - r0) > 65535u * 16u)
         return fail(SRCNN_E_UNSUPPORTED, "output %ux%u too large", dw, dh);
     Workspace& ws = *c.ws;
-    Ctx& cx = *c.cx;
+    [[maybe_unused]] Ctx& cx = *c.cx;
     // rows of layer-2 activations that conv3 touches (clamp-to-edge of the ACTIVATIONS at the true
     // border), and rows of upscaled Y that conv1 touches for those.
     const unsigned ca = r0 >= 2 ? r0 - 2 : 0, cb = std::min(dh, r1 + 2);
     const unsigned ua = ca >= 4 ? ca - 4 : 0, ub = std::min(dh, cb + 4);
     int rc;
     if ((rc = grow_ws(ws, ws.up, ws.up_n, (size_t)dw * (ub - ua)))) return rc;
+#ifndef SRCNN_STRICT_ONLY
     const bool fused = c.mode == SRCNN_MODE_FAST_F16;
     if (fused) {
         // non-parity tier: one kernel for all three layers, no layer-2 planes at all
@@ -811,6 +816,7 @@ int y_path_rows(Call& c, const YSource& src, unsigned w, unsigned h, unsigned dw
         HIP_TRY(hipGetLastError());
         return SRCNN_OK;
     }
+#endif
     if ((rc = grow_ws(ws, ws.c2, ws.c2_n, (size_t)C2N * dw * (cb - ca)))) return rc;
     TraceRange tr("srcnn y_path rows [%u,%u) of %ux%u", r0, r1, dw, dh);
     {
@@ -1133,6 +1139,9 @@ int srcnn_set_mode(int mode)
 {
     if (mode != SRCNN_MODE_STRICT && mode != SRCNN_MODE_FAST && mode != SRCNN_MODE_FAST_F16 && mode != SRCNN_MODE_RELAXED)
         return fail(SRCNN_E_ARG, "bad mode %d", mode);
+#ifdef SRCNN_STRICT_ONLY
+    if (mode != SRCNN_MODE_STRICT) return fail(SRCNN_E_UNSUPPORTED, "this is a strict-only build (make STRICT_ONLY=1): mode %d is not compiled in", mode);
+#endif
     if (mode == SRCNN_MODE_RELAXED) mode |= (int)(G.relax_mask.load() & 0xfu) << 8;
     return G.mode.exchange(mode) & 0xff;
 }
@@ -1537,11 +1546,16 @@ int srcnn_fused_diag(const float* d_up, unsigned w, unsigned h, float* d_out, un
 {
     int rc;
     if ((rc = check_plane(d_up, w, h, d_out))) return rc;
+#ifdef SRCNN_STRICT_ONLY
+    (void)d_dbg; (void)stream;
+    return fail(SRCNN_E_UNSUPPORTED, "strict-only build: the fused fp16 kernel is not compiled in");
+#else
     Ctx* cx = ctx_for_stream(stream);
     if (!cx) return SRCNN_E_NODEVICE;
     launch_fused_f16(d_up, (int)w, (int)h, 0, (int)h, d_out, 0, (int)h, cx->fused_w, cx->num_cus, (hipStream_t)stream, d_dbg);
     HIP_TRY(hipGetLastError());
     return SRCNN_OK;
+#endif
 }
 
 // The switches this process runs with (srcnn_settings.hpp): text into buf (NUL-terminated, truncated to cap), returns the

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/srcnn_amd.h"
+#include "../../include/srcnn_amd_debug.h"
 #include "srcnn_kernels.h"
 #include "srcnn_settings.hpp"
 

@@ -902,7 +902,7 @@ constexpr int c3_mc(bool sdma) { return sdma ? 2 : 4; }
 // 1-channel stages (32 barriers per tile) and 7-8 waves per SIMD (spills) are slower: 3.1 / 5.4 / 8.3 ms.
 // SDMA = false (SRCNN_CONV3_WDMA=0): the register-staged 4-channel form it replaced.
 template <bool STRICT, bool OFF64 = false, bool X64 = false, bool SDMA = false>
-__global__ __launch_bounds__(256, SDMA ? 6 : 1) void k_conv3(
+__global__ __launch_bounds__(256, SDMA ? 6 : 3) void k_conv3(
     const float* __restrict__ C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows,
     float* __restrict__ out, int out_row0, int out_rows, int weights_by_dma)
 {
@@ -1184,6 +1184,7 @@ __global__ __launch_bounds__(256, SDMA ? 6 : 1) void k_conv3(
     }
 }
 
+#ifndef SRCNN_STRICT_ONLY
 // =============================================================================================
 // conv3 for the non-parity tiers: plain fp32 FMA chains.  At 2 VALU cycles per 64 FMAs the strict kernel's
 // one-column-per-lane window (40 ds_read_b32 per 100 FMAs) is LDS-bound, so here a lane owns 2 adjacent
@@ -1285,6 +1286,8 @@ __global__ __launch_bounds__(256) void k_conv3_fast(
         }
     }
 }
+
+#endif  // SRCNN_STRICT_ONLY
 
 // =============================================================================================
 // Unfused layer 1 and layer 2 (stage-level entry points; not used by the hot path).
@@ -1529,9 +1532,11 @@ hipError_t conv12_mfma_prepare()
     hipError_t e;
     if ((e = prep_one<0, true>()) != hipSuccess) return e;
     if ((e = prep_one<0, false>()) != hipSuccess) return e;
+#ifndef SRCNN_STRICT_ONLY            // make STRICT_ONLY=1: no instance of a non-parity kernel is compiled
     if ((e = prep_one<1, true>()) != hipSuccess) return e;
     if ((e = prep_one<2, true>()) != hipSuccess) return e;
     if ((e = prep_one<3, true>()) != hipSuccess) return e;
+#endif
     return hipSuccess;
 }
 
@@ -1555,12 +1560,17 @@ void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows
     const int grid = ntiles >= cap ? cap : (settings().conv12_spread ? std::min(4 * ntiles, cap) : ntiles);
 #define CONV12_GO(R, LD) hipLaunchKernelGGL((k_conv12_mfma<R, LD>), dim3(grid), dim3(64 * M_NW), sizeof(float) * m_lds_floats(LD), s, Y, W, H, \
                                            y_row_base, y_rows, C2, plane_stride, out_row0, out_rows, tiles_x, ntiles, clk, LD ? queue : nullptr)
+#ifdef SRCNN_STRICT_ONLY
+    (void)relax;                     // srcnn_set_mode refuses every other mode in this build
+    if (settings().conv12_dma) CONV12_GO(0, true); else CONV12_GO(0, false);
+#else
     switch (relax & 3) {
     case 0: if (settings().conv12_dma) CONV12_GO(0, true); else CONV12_GO(0, false); break;
     case 1: CONV12_GO(1, true); break;
     case 2: CONV12_GO(2, true); break;
     default: CONV12_GO(3, true); break;
     }
+#endif
 #undef CONV12_GO
 }
 
@@ -1568,6 +1578,7 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
                   int out_row0, int out_rows, int relax, hipStream_t s)
 {
     if (out_rows <= 0) return;
+#ifndef SRCNN_STRICT_ONLY
     const bool strict = !(relax & (RELAX_L3_X64 | RELAX_L3_F32));
     const bool wide_planes = (size_t)c2_rows * (size_t)W * sizeof(float) >= ((size_t)1 << 32);
     if (relax & RELAX_L3_X64) {
@@ -1584,6 +1595,9 @@ void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row
                            out_row0, out_rows);
         return;
     }
+#else
+    (void)relax;
+#endif
     dim3 grid(cdiv(W, 64), cdiv(out_rows, 16));
     const bool force_wide = settings().conv3_off64;      // test hook
     const int wdma = settings().conv3_wdma ? 1 : 0;

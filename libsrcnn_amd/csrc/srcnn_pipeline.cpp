@@ -33,6 +33,12 @@
 namespace srcnn {
 namespace {
 
+// srcnn_debug_process_phases: where the time of the calling thread's last large srcnn_process_u8 / ProcessSRCNN went (share 0
+// of the call; milliseconds since the share's entry).  Written by the thread that runs the share -- the caller's own thread for
+// an image that is not dealt over several contexts.
+struct PhaseRecord { double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; };
+thread_local PhaseRecord g_phases;
+
 bool is_pinned(const void* p)
 {
     hipPointerAttribute_t a;
@@ -626,6 +632,16 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     if (launch_rc) return launch_rc;
     if (e1 != hipSuccess || e2 != hipSuccess || copy_err) return fail(SRCNN_E_HIP, "pipeline failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     HIP_TRY(hipGetLastError());
+    {
+        PhaseRecord& P = g_phases;
+        P.v[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();       // setup: lease, tables, scratch, staging, helper threads
+        P.v[1] = us_first_queued.load() * 1e-3;                                     // first band staged in and its kernels queued
+        P.v[2] = us_kernels_done.load() * 1e-3;                                     // last band's kernels finished on the device
+        P.v[3] = us_landed.load() * 1e-3;                                           // last band's D2H landed (staging or caller's pinned buffer)
+        P.v[4] = std::chrono::duration<double, std::milli>(t2 - t0).count();       // last band fanned out to the caller's buffer
+        P.v[5] = (double)nb;
+        P.n = 6;
+    }
     if (J.trace) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
@@ -644,6 +660,16 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
 using namespace srcnn;
 
 extern "C" {
+
+// Diagnostic: the phase stamps of the calling thread's last large (banded) srcnn_process_u8 / ProcessSRCNN share, in
+// milliseconds since the share began: setup done, first band queued, last kernels done, last band landed, fanned out, and the
+// band count.  Returns how many values exist (0: no banded call ran on this thread), writes at most `cap`.
+int srcnn_debug_process_phases(double* ms, int cap)
+{
+    const PhaseRecord& P = g_phases;
+    for (int i = 0; i < P.n && i < cap; ++i) ms[i] = P.v[i];
+    return P.n;
+}
 
 // Test hook (no device needed): the band cut points srcnn_process_u8 would use for output rows [r0, r1) of a dw-wide image
 // under the current workspace limit.  Writes up to `cap` cut points (first = r0, last = r1), returns how many there are.

@@ -48,6 +48,16 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
                                     (_SESSION_SEED, ", ".join(sorted(_SEEDS_USED))))
 
 
+@pytest.hookimpl(hookwrapper=True)
+def pytest_pyfunc_call(pyfuncitem):
+    """The suite also runs against the strict-only build (SRCNN_AMD_LIB=libsrcnn_amd/lib/strict/libsrcnn_amd.so), which refuses
+    every non-parity mode with SRCNN_E_UNSUPPORTED: a test that asks for one is skipped there, not failed."""
+    outcome = yield
+    exc = outcome.excinfo
+    if exc and getattr(exc[1], "code", None) == -203 and "strict-only build" in str(exc[1]):
+        outcome.force_exception(pytest.skip.Exception("strict-only build: " + str(exc[1])))
+
+
 @pytest.fixture(scope="session")
 def golden():
     class G:

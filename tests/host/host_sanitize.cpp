@@ -23,6 +23,7 @@
 
 #include "../../include/libsrcnn_dropin.h"
 #include "../../include/srcnn_amd.h"
+#include "../../include/srcnn_amd_debug.h"
 #include "../../libsrcnn_amd/csrc/resample_table.hpp"
 #include "../../libsrcnn_amd/csrc/srcnn_watchdog.hpp"
 

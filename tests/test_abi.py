@@ -26,12 +26,23 @@ def _declared_functions(header):
 
 
 def test_header_symbols_exported(S):
+    """The stable ABI is frozen: include/srcnn_amd.h declares exactly the functions of the committed list include/srcnn_amd.abi
+    (and so does the binding), the instruments live in include/srcnn_amd_debug.h, and the library exports both sets.  Adding a
+    function to the stable header without editing the list (and bumping SRCNN_AMD_ABI_VERSION) fails here."""
     names = _declared_functions("srcnn_amd.h")
     assert len(names) >= 40
+    frozen = [ln.strip() for ln in open(os.path.join(ROOT, "include", "srcnn_amd.abi")) if ln.strip() and not ln.startswith("#")]
+    assert frozen == sorted(frozen) and len(set(frozen)) == len(frozen)
+    assert names == frozen, "stable header and include/srcnn_amd.abi disagree: %s" % (set(names) ^ set(frozen))
+    assert sorted(S.STABLE_ABI_SYMBOLS) == frozen, set(S.STABLE_ABI_SYMBOLS) ^ set(frozen)
+    debug = [n for n in _declared_functions("srcnn_amd_debug.h") if n not in names]
+    assert sorted(S.DEBUG_SYMBOLS) == debug, set(S.DEBUG_SYMBOLS) ^ set(debug)
+    assert not any(n.startswith("srcnn_debug_") or n in ("srcnn_fused_diag", "srcnn_set_relaxation") for n in names), "an instrument in the stable header"
+    header = open(os.path.join(ROOT, "include", "srcnn_amd.h")).read()
+    assert "#define SRCNN_AMD_ABI_VERSION 5" in header and "SRCNN_MODE_RELAXED" not in header
     L = S.lib()
-    missing = [n for n in names if not hasattr(L, n)]
+    missing = [n for n in names + debug if not hasattr(L, n)]
     assert not missing, missing
-    assert sorted(S.C_ABI_SYMBOLS) == names, set(S.C_ABI_SYMBOLS) ^ set(names)
 
 
 def test_reference_cxx_symbols_exported(S):
@@ -254,3 +265,28 @@ def test_process_band_plan_random_ranges(S):
                 assert c[-1] - c[-2] <= (r1 - r0) // 4 + 16, c        # short tail
     finally:
         L.srcnn_set_workspace_limit(prev)
+
+
+def test_strict_only_build_has_the_same_abi_and_no_non_parity_kernel(S):
+    """`make STRICT_ONLY=1` / `python -m libsrcnn_amd.build --strict-only`: the same exported symbols as the full library, not one
+    non-parity kernel in the code object (no FAST / FAST_F16 / RELAXED instance), and every mode but STRICT refused with
+    SRCNN_E_UNSUPPORTED -- a setting, so this needs no device."""
+    import subprocess
+    import sys
+    from libsrcnn_amd import build
+    strict, _ = build.build_strict_only(verbose=False)
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported(strict) == exported(S.LIB_PATH)
+    assert os.path.getsize(strict) < os.path.getsize(S.LIB_PATH)
+    blob = open(strict, "rb").read()
+    full = open(S.LIB_PATH, "rb").read()
+    for kernel in (b"k_fused_f16", b"k_conv3_fast", b"k_conv12_mfmaILi3", b"k_conv12_mfmaILi1", b"k_conv12_mfmaILi2"):
+        assert kernel in full and kernel not in blob, kernel
+    assert b"k_conv12_mfmaILi0ELb1" in blob and b"k_conv3ILb1ELb0ELb0ELb1" in blob           # the production strict kernels
+    code = ("import sys; sys.path.insert(0, %r); import libsrcnn_amd as S; L = S.lib();"
+            "print(L.srcnn_abi_version(), L.srcnn_set_mode(1), L.srcnn_set_mode(2), L.srcnn_set_mode(3), L.srcnn_set_mode(0), L.srcnn_get_mode(), L.srcnn_set_mode(9))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_AMD_LIB=strict), capture_output=True, text=True, check=True)
+    assert r.stdout.split() == ["5", "-203", "-203", "-203", "0", "0", "-1"], r.stdout
