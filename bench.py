@@ -269,14 +269,20 @@ def pcie_inclusive(S, frames=16):
         free()
         return {"MPix/s": round(F * 4 * w * h / 1e6 / min(ts), 1), "wall_s_per_frame": round(min(ts) / F, 6),
                 "host_cpu_s_per_frame": round(min(cs) / F, 6)}
-    eager, graph = variant(0), variant(1)
+    eager, graph = variant(0), variant(2)
+    auto = variant(1)
+    g, p, fell = S.stream_mode()
+    auto["last_call_frames_replayed_from_graph"], auto["last_call_frames_launched_plainly"], auto["fell_back_to_plain_launches"] = g, p, bool(fell) or p == F
     return {"value": graph["MPix/s"], "unit": "MPix/s", "frames": F, "best_of": 3,
+            "use_graph_auto": auto,
             "bytes_per_output_px": {"h2d": 1.0, "d2h": 4.0},
             "host_cpu_s_per_frame": graph["host_cpu_s_per_frame"], "wall_s_per_frame": graph["wall_s_per_frame"],
             "plain_launches": eager,
             "note": "planar f32 Y frames in page-locked host memory, H2D + path + D2H overlapped over two slots "
-                    "(srcnn_y_upscale2x_f32_stream); `value` = with one hipGraph per slot as BASELINE config #5 asks, "
-                    "`plain_launches` = the same stream without graphs.  host_cpu_s_per_frame = process CPU time (all "
+                    "(srcnn_y_upscale2x_f32_stream); `value` = with one hipGraph per slot as BASELINE config #5 asks (use_graph = 2: "
+                    "replay insisted on), `plain_launches` = the same stream without graphs (use_graph = 0), `use_graph_auto` = use_graph "
+                    "= 1: replay kept only while its host CPU cost stays below SRCNN_GRAPH_MAX_CPU_PCT of a frame, otherwise plain "
+                    "launches.  host_cpu_s_per_frame = process CPU time (all "
                     "threads) per frame: the library's threads sleep or poll; with graph replay a thread of the ROCm "
                     "runtime stays busy from launch to completion (tools/runtime_thread_probe.py).  Never the headline value"}
 
@@ -694,7 +700,7 @@ def side_workload(args):
                 "the kernels of k+1) + RCCL gatherv to rank 0" % (w, h, 2 * w, 2 * h, world, tiled.nsub)
     elif args.workload == "host-stream":
         F = max(args.frames, 16)          # one call = one stream of F frames; the first H2D and the last D2H of a call are exposed
-        step, cleanup = host_stream_setup(S, F, 0 if args.plain_launches else 1)
+        step, cleanup = host_stream_setup(S, F, 0 if args.plain_launches else 2)
         mpix_step = world * F * 4 * IN_W * IN_H / 1e6
         label = "stream of %d host-resident (page-locked) 3840x2160 Y frames per rank per step: H2D + path + D2H over two " \
                 "slots, %s (BASELINE config #5 shape), frames sharded %d-way" % (

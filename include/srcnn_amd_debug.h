@@ -67,6 +67,11 @@ int srcnn_debug_band_plan(unsigned r0, unsigned r1, unsigned dw, int one_of_many
  * ms[5]: the number of bands.  Returns how many values exist (0: no banded call on this thread yet), writes at most cap. */
 int srcnn_debug_process_phases(double* ms, int cap);
 
+/* Diagnostic: how the process's last srcnn_y_upscale2x_f32_stream call launched its frames, summed over the contexts:
+ * frames replayed from a hipGraph, frames launched plainly, and whether use_graph = 1 retired its graphs because replay
+ * burnt host CPU (SRCNN_GRAPH_MAX_CPU_PCT).  Any pointer may be NULL. */
+int srcnn_debug_stream_mode(unsigned* graph_frames, unsigned* plain_frames, int* fell_back);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ STABLE_ABI_SYMBOLS = [
 # instruments (include/srcnn_amd_debug.h): test hooks, diagnostics, the relaxation experiment -- no compatibility promise
 DEBUG_SYMBOLS = [
     "srcnn_set_relaxation", "srcnn_axis_table", "srcnn_fused_diag", "srcnn_debug_counts", "srcnn_debug_settings",
-    "srcnn_debug_clock_probe", "srcnn_debug_clock_read", "srcnn_debug_band_plan", "srcnn_debug_process_phases",
+    "srcnn_debug_clock_probe", "srcnn_debug_clock_read", "srcnn_debug_band_plan", "srcnn_debug_process_phases", "srcnn_debug_stream_mode",
 ]
 C_ABI_SYMBOLS = STABLE_ABI_SYMBOLS + DEBUG_SYMBOLS          # everything the library exports besides the two C++ symbols
 CXX_SYMBOLS = ["_Z20ConfigureFilterSRCNN15SRCNNFilterTypeb", "_Z12ProcessSRCNNPKhjjjfRPhRjPS1_Pj"]
@@ -340,12 +340,21 @@ def y_upscale2x_batch(frames):
 
 
 def y_upscale2x_stream(frames, use_graph=True):
-    """srcnn_y_upscale2x_f32_stream: host frames in/out, two slots, optional hipGraph replay per slot."""
+    """srcnn_y_upscale2x_f32_stream.  use_graph: False / 0 = plain launches, True / 2 = hipGraph replay whatever it costs,
+    "auto" / 1 = replay kept only while it is cheap in host CPU (stream_mode() says what ran)."""
     frames = np.ascontiguousarray(frames, np.float32)
     n, h, w = frames.shape
     out = np.empty((n, 2 * h, 2 * w), np.float32)
-    check(lib().srcnn_y_upscale2x_f32_stream(frames.ctypes.data, w, h, n, out.ctypes.data, 1 if use_graph else 0))
+    g = 1 if use_graph == "auto" else (int(use_graph) if isinstance(use_graph, int) and not isinstance(use_graph, bool) else (2 if use_graph else 0))
+    check(lib().srcnn_y_upscale2x_f32_stream(frames.ctypes.data, w, h, n, out.ctypes.data, g))
     return out
+
+
+def stream_mode():
+    """(frames replayed from a hipGraph, frames launched plainly, fell back?) of the process's last stream call."""
+    g, p, f = C.c_uint(0), C.c_uint(0), C.c_int(0)
+    check(lib().srcnn_debug_stream_mode(C.byref(g), C.byref(p), C.byref(f)))
+    return g.value, p.value, bool(f.value)
 
 
 def y_path(y, dw, dh, filt=SRCNNF_Bicubic):

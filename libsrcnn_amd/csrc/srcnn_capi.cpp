@@ -22,6 +22,9 @@
 
 #include "resample_table.hpp"
 #include <chrono>
+#include <sys/auxv.h>
+#include <unistd.h>
+
 #include "srcnn_host.hpp"
 
 namespace srcnn {
@@ -81,16 +84,48 @@ TraceRange::~TraceRange() { if (on_) (void)roctx().pop(); }
 Settings Settings::from_env()
 {
     Settings st;
+    // A switch that is set but not understood used to be dropped in silence (SRCNN_TRACE=yes read as 0; a retired switch of an
+    // earlier round measured the production path and reported it as a variant): every such case is now said once, on stderr.
+    auto warn = [](const char* fmt, const char* a, const char* b) { fprintf(stderr, fmt, a, b); };
     auto get = [](const char* name) -> const char* { const char* v = getenv(name); return (v && *v) ? v : nullptr; };
-#define SRCNN_GET_B(m) st.m = atoi(v) != 0;
-#define SRCNN_GET_I(m) st.m = strtol(v, nullptr, 10);
-#define SRCNN_GET_S(m) st.m = v;
-#define X(kind, member, env, def, values, effect) if (const char* v = get(env)) { SRCNN_GET_##kind(member) }
+    auto parse_b = [&](const char* env, const char* v, bool& dst) {
+        for (const char* t : {"1", "true", "yes", "on", "TRUE", "YES", "ON"}) if (!strcmp(v, t)) { dst = true; return; }
+        for (const char* t : {"0", "false", "no", "off", "FALSE", "NO", "OFF"}) if (!strcmp(v, t)) { dst = false; return; }
+        char* end = nullptr;
+        const long n = strtol(v, &end, 10);
+        if (end != v && *end == 0) { dst = n != 0; return; }
+        warn("libsrcnn_amd: %s=%s is not a boolean (0/1, yes/no, on/off, true/false): the default stays\n", env, v);
+    };
+    auto parse_i = [&](const char* env, const char* v, long& dst) {
+        char* end = nullptr;
+        const long n = strtol(v, &end, 10);
+        if (end != v && *end == 0) dst = n;
+        else warn("libsrcnn_amd: %s=%s is not an integer: the default stays\n", env, v);
+    };
+    // SRCNN_RCCL_LIB names code to load into the process: like LD_PRELOAD it is not honoured under secure execution
+    const bool secure = getauxval(AT_SECURE) != 0;
+#define SRCNN_GET_B(m) parse_b(name, v, st.m);
+#define SRCNN_GET_I(m) parse_i(name, v, st.m);
+#define SRCNN_GET_S(m) if (secure && !strcmp(name, "SRCNN_RCCL_LIB")) warn("libsrcnn_amd: %s=%s ignored: secure-execution (set-uid / set-gid / capabilities) process\n", name, v); else st.m = v;
+#define X(kind, member, env, def, values, effect) if (const char* v = get(env)) { const char* name = env; (void)name; SRCNN_GET_##kind(member) }
     SRCNN_SETTINGS(X)
 #undef X
 #undef SRCNN_GET_B
 #undef SRCNN_GET_I
 #undef SRCNN_GET_S
+    // anything else that looks like one of ours: said once (names the tests, the bench and the build recipes use are not switches
+    // of the library and pass)
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "SRCNN_", 6) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+        bool known = false;
+#define X(kind, member, env, def, values, effect) if (name == env) known = true;
+        SRCNN_SETTINGS(X)
+#undef X
+        if (known || name == "SRCNN_TEST_SEED" || name == "SRCNN_AMD_LIB" || name == "SRCNN_FUSED_CFLAGS" || name.rfind("SRCNN_BENCH_", 0) == 0) continue;
+        warn("libsrcnn_amd: %s is not a switch of this library (see srcnn_debug_settings / DESIGN.md 6)%s: ignored\n", name.c_str(), "");
+    }
     st.max_workspace_mb = std::max(st.max_workspace_mb, 1L);
     st.max_lanes = std::min(64L, std::max(1L, st.max_lanes));
     st.comm_timeout_ms = std::max(0L, st.comm_timeout_ms);

@@ -20,6 +20,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/auxv.h>
+
 #include "../../include/srcnn_amd.h"
 
 #include "srcnn_host.hpp"
@@ -139,6 +141,14 @@ int load()
     // SRCNN_RCCL_LIB: an explicit library, consulted first and alone (a site build of RCCL; the test-suite's stand-in that
     // moves data between processes sharing ONE device, tests/rccl_double/ -- the installed RCCL refuses two ranks per device)
     if (const char* path = srcnn::settings().rccl_lib.empty() ? nullptr : srcnn::settings().rccl_lib.c_str()) {
+        // A TRUST BOUNDARY: this loads and runs whatever the environment names, with the process's privileges -- the same
+        // power LD_PRELOAD has, and refused in the same situation: a process the kernel marked secure (set-uid / set-gid /
+        // file capabilities: AT_SECURE) ignores the variable's intent and fails instead of loading it.
+        if (getauxval(AT_SECURE)) {
+            snprintf(g_cerr, sizeof g_cerr, "SRCNN_RCCL_LIB is refused in a secure-execution (set-uid / set-gid / capabilities) process");
+            srcnn::set_last_error(g_cerr);
+            return SRCNN_E_COMM;
+        }
         h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         if (!h) {
             snprintf(g_cerr, sizeof g_cerr, "dlopen(SRCNN_RCCL_LIB=%s) failed: %s", path, dlerror());

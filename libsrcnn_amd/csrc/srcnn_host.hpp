@@ -124,6 +124,7 @@ struct StreamSlot {         // one lane of the host-stream path; lives until src
     hipGraphExec_t exec = nullptr;     // captured kernel sequence for (gw, gh, gmode)
     unsigned gw = 0, gh = 0; int gmode = -1;
     unsigned uses = 0;                 // eager runs at the current shape (capture needs one first)
+    int graph_verdict = 0;             // use_graph == 1 ("auto"): 0 = not measured yet, 1 = replay is cheap, 2 = replay burns host CPU: plain launches
 };
 
 // One lane of srcnn_process_u8 (the ProcessSRCNN surface).  The reference's ProcessSRCNN allocates everything per

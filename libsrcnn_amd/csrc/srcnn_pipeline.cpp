@@ -39,6 +39,16 @@ namespace {
 struct PhaseRecord { double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; };
 thread_local PhaseRecord g_phases;
 
+// srcnn_debug_stream_mode: how the frames of the process's last srcnn_y_upscale2x_f32_stream call were launched
+std::atomic<unsigned> g_stream_graph_frames{0}, g_stream_plain_frames{0};
+std::atomic<int> g_stream_fell_back{0};
+
+double process_cpu_seconds()
+{
+    timespec ts;
+    return clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec : 0.0;
+}
+
 bool is_pinned(const void* p)
 {
     hipPointerAttribute_t a;
@@ -121,6 +131,7 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
         if (!rc && !sl.cst && hipStreamCreateWithFlags(&sl.cst, hipStreamNonBlocking) != hipSuccess) rc = fail(SRCNN_E_HIP, "stream create");
         for (hipEvent_t* e : {&sl.e_in, &sl.e_k, &sl.e_out})
             if (!rc && !*e && hipEventCreateWithFlags(e, kBlockingEvent) != hipSuccess) rc = fail(SRCNN_E_HIP, "event create");
+        if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) sl.graph_verdict = 0;
         if (!rc && (sl.gw != w || sl.gh != h || sl.gmode != mode)) {     // shape or mode changed: drop the graph first,
             if (sl.exec) { (void)wait_stream(cx.slots[0].st); (void)hipGraphExecDestroy(sl.exec); sl.exec = nullptr; }
             sl.ws.frozen = false;                                          // then its buffers may move again
@@ -159,8 +170,27 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
     hipStream_t ks = cx.slots[0].st;       // ALL kernels go to one stream: frames back to back, never two frames' kernels
                                            // sharing the chip (that costs more than it overlaps: the persistent layer-1+2
                                            // kernel partitions its tiles over the workgroups it expects to be resident)
+    // use_graph: 0 = plain launches; 2 = one hipGraph per slot, replayed per frame, whatever it costs; 1 = the same, KEPT ONLY
+    // IF IT IS CHEAP: the process's CPU time over the first replayed frames is held against their wall time, and when a replay
+    // costs more than SRCNN_GRAPH_MAX_CPU_PCT of a frame (on ROCm 7.2 a runtime thread spins from graph launch to completion:
+    // 9.9 ms of CPU per 9.5 ms 4K frame, against 0.6 ms for the plain launches, at the same throughput -- profiles/r05_bench.json)
+    // the graphs are retired and the stream goes on with plain launches.  The verdict is remembered per slot and shape.
+    constexpr unsigned kProbeFrames = 4;
+    const long max_pct = settings().graph_max_cpu_pct;
+    unsigned probe_replays = 0;
+    double probe_cpu0 = 0.0;
+    std::chrono::steady_clock::time_point probe_t0;
     for (unsigned f = 0; f < nframes && !rc; ++f) {
         StreamSlot& sl = cx.slots[f % nslots];
+        if (use_graph == 1 && max_pct > 0 && probe_replays == kProbeFrames && cx.slots[0].graph_verdict == 0) {
+            // the slot of this frame has been waited for below in the previous round: kProbeFrames replays lie (almost) behind us
+            const double cpu = process_cpu_seconds() - probe_cpu0;
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - probe_t0).count();
+            const int verdict = (wall > 0 && cpu * 100.0 > wall * (double)max_pct) ? 2 : 1;
+            for (int i = 0; i < nslots; ++i) cx.slots[i].graph_verdict = verdict;
+            if (verdict == 2) g_stream_fell_back = 1;
+        }
+        const bool graph_now = use_graph == 2 || (use_graph == 1 && sl.graph_verdict != 2) || (use_graph != 0 && use_graph != 1 && use_graph != 2);
         Call c;
         c.cx = &cx; c.s = ks; c.ws = &sl.ws; c.mode = mode; c.hold = &sl.tables;
         if (f >= (unsigned)nslots) {
@@ -174,7 +204,7 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
             hipEventRecord(sl.e_in, sl.cst) != hipSuccess || wait_event(sl.e_in) != hipSuccess) {
             rc = fail(SRCNN_E_HIP, "H2D"); break;
         }
-        if (use_graph && sl.uses >= 1 && !sl.exec) {
+        if (graph_now && sl.uses >= 1 && !sl.exec) {
             // The slot has run this shape eagerly once: tables and workspaces exist, so the kernel sequence
             // can be captured without any allocation inside the capture.  The graph's table references are kept apart
             // from the eager runs' (which trim theirs), for exactly as long as the graph lives.
@@ -194,9 +224,13 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
             if (graph) (void)hipGraphDestroy(graph);
             if (rc) { sl.ws.frozen = false; sl.graph_tables.clear(); break; }
         }
-        if (use_graph && sl.exec) {
+        if (graph_now && sl.exec) {
+            if (probe_replays == 0) { probe_cpu0 = process_cpu_seconds(); probe_t0 = std::chrono::steady_clock::now(); }
             if (hipGraphLaunch(sl.exec, ks) != hipSuccess) { rc = fail(SRCNN_E_HIP, "graph launch"); break; }
+            ++probe_replays;
+            ++g_stream_graph_frames;
         } else {
+            ++g_stream_plain_frames;
             if (sl.exec) {
                 // an eager call (use_graph == 0) on a slot that still holds a captured graph of this shape: retire the graph
                 // first.  Its workspace is frozen (pointers baked in), so an eager run that needs more scratch -- a larger
@@ -661,6 +695,17 @@ using namespace srcnn;
 
 extern "C" {
 
+// Diagnostic: how the process's last srcnn_y_upscale2x_f32_stream call launched its frames (summed over the contexts): frames
+// replayed from a hipGraph, frames launched plainly (the first frame of a slot always is: capture needs one eager run), and
+// whether use_graph = 1 gave the graphs up because replay burnt host CPU (SRCNN_GRAPH_MAX_CPU_PCT).
+int srcnn_debug_stream_mode(unsigned* graph_frames, unsigned* plain_frames, int* fell_back)
+{
+    if (graph_frames) *graph_frames = g_stream_graph_frames.load();
+    if (plain_frames) *plain_frames = g_stream_plain_frames.load();
+    if (fell_back) *fell_back = g_stream_fell_back.load();
+    return SRCNN_OK;
+}
+
 // Diagnostic: the phase stamps of the calling thread's last large (banded) srcnn_process_u8 / ProcessSRCNN share, in
 // milliseconds since the share began: setup done, first band queued, last kernels done, last band landed, fanned out, and the
 // band count.  Returns how many values exist (0: no banded call ran on this thread), writes at most `cap`.
@@ -719,6 +764,7 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
     const size_t in_n = (size_t)w * h, out_n = in_n * 4;
     const size_t in_b = in_n * sizeof(float), out_b = out_n * sizeof(float);
     const int mode = G.mode.load();
+    g_stream_graph_frames = 0; g_stream_plain_frames = 0; g_stream_fell_back = 0;
 
     // page-lock the caller's frames so the copies are truly asynchronous -- unless they already are (buffers from
     // srcnn_host_alloc_pinned / hipHostMalloc: registering a gigabyte again costs milliseconds per call); harmless if it fails

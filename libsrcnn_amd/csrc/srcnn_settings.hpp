@@ -19,11 +19,12 @@
     X(B, numa,             "SRCNN_NUMA",             1,     "0/1", "place page-locked staging on the device's NUMA node (the caller's memory policy is saved and restored)") \
     X(I, comm_timeout_ms,  "SRCNN_COMM_TIMEOUT_MS",  60000, "ms, 0 = none (API twin `srcnn_comm_set_timeout_ms`)", "deadline of every wait on a peer") \
     X(B, comm_check,       "SRCNN_COMM_CHECK",       1,     "0/1", "all-reduce a checksum of every new gather table across the ranks before the first gather that uses it") \
-    X(S, rccl_lib,         "SRCNN_RCCL_LIB",         "",    "path", "load this RCCL instead of the one next to the bound `libamdhip64` (site builds; the test-suite's one-device stand-in)") \
+    X(S, rccl_lib,         "SRCNN_RCCL_LIB",         "",    "path", "load this RCCL instead of the one next to the bound `libamdhip64` (site builds; the test-suite's one-device stand-in).  A trust boundary: the named file's code runs in the process; refused under secure execution (`AT_SECURE`)") \
     X(I, async_chain,      "SRCNN_ASYNC_CHAIN",      1,     "0/1/2", "order the kernels of consecutive asynchronous `ProcessSRCNN` jobs: 0 = not at all, 1 = on the host, 2 = with device-side event waits") \
     X(B, trace,            "SRCNN_TRACE",            0,     "0/1", "one stderr line per `srcnn_process_u8` share (setup / bands / stamps)") \
     X(B, roctx,            "SRCNN_ROCTX",            0,     "0/1", "roctx ranges for `rocprofv3 --marker-trace`") \
     X(S, bands,            "SRCNN_BANDS",            "",    "`f0,f1,...`", "band fractions of a large `ProcessSRCNN` image instead of the planned cuts") \
+    X(I, graph_max_cpu_pct, "SRCNN_GRAPH_MAX_CPU_PCT", 50,  "0...100, 0 = never fall back", "`srcnn_y_upscale2x_f32_stream(use_graph = 1)`: hipGraph replay is kept only while the process's CPU time per replayed frame stays below this share of the frame's wall time (on ROCm 7.2 a runtime thread spins from launch to completion: ~100 %); above it the stream goes on with plain launches -- same kernels, same overlap") \
     X(B, prefault,         "SRCNN_PREFAULT",         1,     "0/1", "pre-fault the fresh result pages of `ProcessSRCNN` in the background") \
     X(I, prefault_threads, "SRCNN_PREFAULT_THREADS", 1,     ">= 1", "helpers of that pre-faulting") \
     X(B, thp,              "SRCNN_THP",              1,     "0/1", "huge-page hint on large result blocks") \

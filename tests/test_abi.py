@@ -290,3 +290,59 @@ def test_strict_only_build_has_the_same_abi_and_no_non_parity_kernel(S):
             "print(L.srcnn_abi_version(), L.srcnn_set_mode(1), L.srcnn_set_mode(2), L.srcnn_set_mode(3), L.srcnn_set_mode(0), L.srcnn_get_mode(), L.srcnn_set_mode(9))" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_AMD_LIB=strict), capture_output=True, text=True, check=True)
     assert r.stdout.split() == ["5", "-203", "-203", "-203", "0", "0", "-1"], r.stdout
+
+
+def test_rccl_lib_override_is_refused_under_secure_execution(S, tmp_path):
+    """SRCNN_RCCL_LIB makes the library dlopen a file named by the environment: a trust boundary.  Like
+    LD_PRELOAD it must not work in a process the kernel marked secure (AT_SECURE: set-uid / set-gid / file capabilities).
+    Needs root and a mount that honours set-uid bits to stage such a process; skipped otherwise."""
+    import shutil
+    import subprocess
+    if os.geteuid() != 0 or not shutil.which("gcc"):
+        pytest.skip("needs root (to hand a set-uid binary to another user) and gcc")
+    src = tmp_path / "secure_probe.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include <sys/auxv.h>\n#include "srcnn_amd_debug.h"\n'
+                   'int main(void) { static char buf[16384]; srcnn_debug_settings(buf, sizeof buf, 0);\n'
+                   '  char* p = strstr(buf, "SRCNN_RCCL_LIB="); char* e = p ? strchr(p, \' \') : 0; if (e) *e = 0;\n'
+                   '  printf("%lu|%s\\n", getauxval(AT_SECURE), p ? p : "?"); return 0; }\n')
+    import tempfile
+    # the probe runs as `nobody`: library and binary go where that user can reach them (not under /root, not under pytest's 0700 tmp)
+    stage = tempfile.mkdtemp(prefix="srcnn_secure_", dir="/tmp")
+    try:
+        os.chmod(stage, 0o755)
+        shutil.copy(S.LIB_PATH, os.path.join(stage, "libsrcnn_amd.so"))
+        exe = os.path.join(stage, "secure_probe")
+        subprocess.run(["gcc", str(src), "-I", os.path.join(ROOT, "include"), "-L", stage, "-lsrcnn_amd", "-Wl,-rpath," + stage, "-o", exe], check=True)
+        os.chown(exe, 65534, 65534)
+        os.chmod(exe, 0o4755)
+        env = dict(os.environ, SRCNN_RCCL_LIB="/nonexistent/librccl_from_the_environment.so")
+        plain = subprocess.run([exe], env=dict(env, SRCNN_RCCL_LIB=""), capture_output=True, text=True)
+        r = subprocess.run([exe], env=env, capture_output=True, text=True)
+    finally:
+        shutil.rmtree(stage, ignore_errors=True)
+    if r.returncode != 0 or not r.stdout.startswith("1|"):
+        pytest.skip("this mount does not honour set-uid bits (AT_SECURE stayed 0) or the probe could not run: " + r.stdout + r.stderr)
+    assert r.stdout.strip() == "1|SRCNN_RCCL_LIB=(unset)", r.stdout                  # not honoured ...
+    assert "SRCNN_RCCL_LIB=/nonexistent/librccl_from_the_environment.so ignored: secure-execution" in r.stderr      # ... and said so
+    assert plain.stdout.strip() == "1|SRCNN_RCCL_LIB=(unset)" and "ignored" not in plain.stderr
+    # the same probe in an ordinary process honours the variable
+    code = "import sys; sys.path.insert(0, %r); import libsrcnn_amd as S; print([l for l in S.debug_settings().splitlines() if 'RCCL_LIB' in l][0])" % ROOT
+    import sys
+    o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    assert o.startswith("SRCNN_RCCL_LIB=/nonexistent/librccl_from_the_environment.so "), o
+
+
+def test_switches_that_are_not_understood_are_said_once(S):
+    """A retired or misspelt SRCNN_* switch and a value that does not parse are reported on stderr when the library is loaded
+    (an A/B script that still exports a round-4 name would otherwise measure the production path and call it a variant);
+    the words people write for booleans are understood."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); import libsrcnn_amd as S; print(S.debug_settings())" % ROOT
+    env = dict(os.environ, SRCNN_CONV12_VARIANT="2", SRCNN_TRACE="yes", SRCNN_MAX_LANES="many", SRCNN_THP="off", SRCNN_TEST_SEED="5",
+               SRCNN_BENCH_FAKE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+    assert "SRCNN_CONV12_VARIANT is not a switch of this library" in r.stderr
+    assert "SRCNN_MAX_LANES=many is not an integer" in r.stderr
+    assert "SRCNN_TEST_SEED" not in r.stderr and "SRCNN_BENCH_FAKE" not in r.stderr and "SRCNN_TRACE" not in r.stderr
+    assert "SRCNN_TRACE=1 (default 0)" in r.stdout and "SRCNN_THP=0 (default 1)" in r.stdout and "SRCNN_MAX_LANES=4 (default 4)" in r.stdout

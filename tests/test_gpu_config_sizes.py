@@ -1,6 +1,6 @@
 """GPU: BASELINE.json configs #4 and #5 at their STATED counts (missing #3 / next item 6).
   #5  "stream of 512 4K frames ... per-GPU hipGraph capture": 512 frames of 3840x2160 -> 7680x4320 through
-      srcnn_y_upscale2x_f32_stream(use_graph = 1), from a pool of 8 page-locked inputs into a ring of 8 page-locked outputs;
+      srcnn_y_upscale2x_f32_stream(use_graph = 2: replay insisted on), from a pool of 8 page-locked inputs into a ring of 8 page-locked outputs;
       every 64th frame is compared with the single-frame call, one of them with an oracle window; host memory and thread
       count must be flat over the run.
   #4  "single 8K frame tiled across 8 MI355X": one 7680x4320 frame -> 15360x8640 over 8 contexts of one process (node call),
@@ -42,7 +42,7 @@ def test_config5_512_frames_streamed_with_hipgraph_replay(srcnn, oracle_lib):
             # the pool is refilled as a real feeder would: slot c % 8 gets a new frame before every call
             slot = c % POOL
             pin_in.array[slot] = np.roll(base[c & 1], 11 * c + 5, axis=0)
-            S.check(L.srcnn_y_upscale2x_f32_stream(pin_in.ptr, w, h, POOL, pin_out.ptr, 1))
+            S.check(L.srcnn_y_upscale2x_f32_stream(pin_in.ptr, w, h, POOL, pin_out.ptr, 2))
             if c % 8 == 0:                                     # frame index 8*c is a multiple of 64: slot 0 of this call
                 src = np.array(pin_in.array[0])
                 got = np.array(pin_out.array[0])

@@ -561,3 +561,48 @@ def test_canaries_around_processsrcnn_host_outputs(srcnn, oracle_lib, shape, d, 
         assert (buf[:CANARY] == 0xA5).all() and (buf[-CANARY:] == 0xA5).all()
     assert np.array_equal(out[CANARY:-CANARY].reshape(want_rgb.shape), want_rgb)
     assert np.array_equal(conv[CANARY:-CANARY].reshape(want_conv.shape), want_conv)
+
+
+@pytest.mark.gpu
+def test_stream_use_graph_auto_is_cheap_in_host_cpu_by_default(srcnn):
+    """srcnn_y_upscale2x_f32_stream(use_graph = 1) keeps hipGraph replay only while it is cheap.  On ROCm 7.2
+    a replay pins a runtime thread for the frame's duration (~10 ms of CPU per 4K frame, 0.6 ms for plain launches): the
+    first call measures its first four replays and falls back; from then on the shape runs on plain launches and costs
+    < 1 ms of process CPU per frame.  Whatever the runtime does, what ran is reported, the results are the single-frame
+    results, and use_graph = 2 still replays every frame but the slots' first ones."""
+    import ctypes as C
+    import time
+    S = srcnn
+    L = S.lib()
+    w, h, F = 3840, 2160, 12
+    pin_in = S.PinnedArray((F, h, w), np.float32)
+    pin_out = S.PinnedArray((F, 2 * h, 2 * w), np.float32)
+    try:
+        two = synth.frames(2, h, w, 7, "smooth")
+        for f in range(F):
+            pin_in.array[f] = two[f & 1]
+        want = [S.y_upscale2x(two[0]), S.y_upscale2x(two[1])]
+
+        def run(g):
+            c0, t0 = time.process_time(), time.perf_counter()
+            S.check(L.srcnn_y_upscale2x_f32_stream(pin_in.array.ctypes.data, w, h, F, pin_out.array.ctypes.data, g))
+            return (time.process_time() - c0) / F, (time.perf_counter() - t0) / F, S.stream_mode()
+        cpu1, wall1, (g1, p1, fell1) = run(1)                      # first auto call: eager frames, capture, probe, verdict
+        assert g1 + p1 == F
+        for f in (0, 5, F - 1):
+            assert_bit_equal(pin_out.array[f], want[f & 1], "auto, frame %d" % f)
+        cpu2, wall2, (g2, p2, fell2) = run(1)                      # the verdict is remembered
+        assert g2 + p2 == F
+        if fell1:
+            assert g1 <= 5 and (g2, p2) == (0, F), ((g1, p1), (g2, p2))
+        else:
+            assert g2 >= F - 2                                     # a runtime whose replay is cheap keeps its graphs
+        assert cpu2 < 1e-3, "use_graph=1 costs %.2f ms of host CPU per frame (wall %.2f ms; mode %s)" % (cpu2 * 1e3, wall2 * 1e3, (g2, p2, fell2))
+        cpu3, wall3, (g3, p3, fell3) = run(2)                      # forced: every frame but the slots' first (eager) ones
+        assert g3 >= F - 2 and not fell3, (g3, p3, fell3)
+        for f in (1, F - 1):
+            assert_bit_equal(pin_out.array[f], want[f & 1], "forced graph, frame %d" % f)
+        print("use_graph auto: first call %s cpu %.2f ms/frame, second %s cpu %.2f ms/frame (wall %.2f); forced graph cpu %.2f ms/frame (wall %.2f)"
+              % ((g1, p1, fell1), cpu1 * 1e3, (g2, p2, fell2), cpu2 * 1e3, wall2 * 1e3, cpu3 * 1e3, wall3 * 1e3))
+    finally:
+        pin_in.free(); pin_out.free()
