@@ -299,7 +299,7 @@ int make_context_locked(int device)
         Ctx* cx;
         ~FreeOnError() { if (cx) { (void)hipFree(cx->fused_w); cx->fused_w = nullptr; } }
     } guard{cx.get()};
-    HIP_TRY(hipMemcpy(cx->fused_w, fw.get(), sizeof(FusedF16Weights), hipMemcpyHostToDevice));
+    if (int rc = copy_h2d_any(*cx, cx->fused_w, fw.get(), sizeof(FusedF16Weights), nullptr)) return rc;
     HIP_TRY(fused_f16_prepare());
     HIP_TRY(rs2d_prepare());
     guard.cx = nullptr;
@@ -425,9 +425,10 @@ int get_table(Call& c, int filter, unsigned dst_len, unsigned src_len, TableRef&
         HIP_TRY(hipMalloc((void**)&d->first, sizeof(int) * dst_len));
         HIP_TRY(hipMalloc((void**)&d->taps, sizeof(int) * dst_len));
         HIP_TRY(hipMalloc((void**)&d->weight, sizeof(double) * t.weight.size()));
-        HIP_TRY(hipMemcpy(d->first, t.first.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d->taps, t.taps.data(), sizeof(int) * dst_len, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d->weight, t.weight.data(), sizeof(double) * t.weight.size(), hipMemcpyHostToDevice));
+        // (heap vectors: through the bounce slots like every other pageable source -- a tall frame's weight table is 400 KB)
+        if (int rc = copy_h2d_any(cx, d->first, t.first.data(), sizeof(int) * dst_len, nullptr)) return rc;
+        if (int rc = copy_h2d_any(cx, d->taps, t.taps.data(), sizeof(int) * dst_len, nullptr)) return rc;
+        if (int rc = copy_h2d_any(cx, d->weight, t.weight.data(), sizeof(double) * t.weight.size(), nullptr)) return rc;
         if (cx.tables.size() >= kMaxTables) {
             // evict the least recently used tables that only the cache still references, down to half the bound.
             // Kernels launched by calls that already returned may still be reading them, hence the drain first.
@@ -511,6 +512,96 @@ void* pinned_alloc(Ctx& cx, size_t bytes)
     }
     if (!p) fail(SRCNN_E_DEVMEM, "hipHostMalloc(%zu) failed", bytes);
     return p;
+}
+
+bool host_is_page_locked(const void* p)
+{
+    hipPointerAttribute_t a;
+    const bool yes = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return yes;
+}
+
+void HostBounce::release()
+{
+    if (pin) (void)hipHostFree(pin);
+    if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    pin = nullptr; st = nullptr;
+}
+
+namespace {
+int bounce_ready(Ctx& cx, HostBounce& b)          // b.mu held
+{
+    if (!b.pin && !(b.pin = static_cast<unsigned char*>(pinned_alloc(cx, 2 * HostBounce::kSlot)))) return SRCNN_E_DEVMEM;
+    if (!b.st) HIP_TRY(hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking));
+    for (hipEvent_t& e : b.ev)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return SRCNN_OK;
+}
+}  // namespace
+
+int copy_h2d_any(Ctx& cx, void* d_dst, const void* h_src, size_t bytes, hipStream_t after)
+{
+    if (bytes == 0) return SRCNN_OK;
+    if (pinned_by_library(h_src, bytes) || host_is_page_locked(h_src)) {
+        if (after) HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, after));
+        else HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+        return SRCNN_OK;
+    }
+    // ordered like the copy it replaces: behind what is queued on `after` (NULL: the default stream, as hipMemcpy is)
+    if (wait_stream(after) != hipSuccess) return fail(SRCNN_E_HIP, "stream failed before a host-to-device copy");
+    HostBounce& b = cx.bounce;
+    std::lock_guard<std::mutex> lk(b.mu);
+    if (int rc = bounce_ready(cx, b)) return rc;
+    const unsigned char* src = static_cast<const unsigned char*>(h_src);
+    unsigned char* dst = static_cast<unsigned char*>(d_dst);
+    bool used[2] = {false, false};
+    for (size_t off = 0, i = 0; off < bytes; off += HostBounce::kSlot, ++i) {
+        const int k = (int)(i & 1);
+        const size_t len = std::min(HostBounce::kSlot, bytes - off);
+        if (used[k] && wait_event(b.ev[k]) != hipSuccess) return fail(SRCNN_E_HIP, "bounced H2D copy failed");
+        parallel_memcpy(b.pin + k * HostBounce::kSlot, src + off, len);
+        HIP_TRY(hipMemcpyAsync(dst + off, b.pin + k * HostBounce::kSlot, len, hipMemcpyHostToDevice, b.st));
+        HIP_TRY(hipEventRecord(b.ev[k], b.st));
+        used[k] = true;
+    }
+    if (wait_stream(b.st) != hipSuccess) return fail(SRCNN_E_HIP, "bounced H2D copy failed");
+    return SRCNN_OK;
+}
+
+int copy_d2h_any(Ctx& cx, void* h_dst, const void* d_src, size_t bytes, hipStream_t after)
+{
+    if (bytes == 0) return SRCNN_OK;
+    if (pinned_by_library(h_dst, bytes) || host_is_page_locked(h_dst)) {
+        if (after) HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, after));
+        else HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+        return SRCNN_OK;
+    }
+    if (wait_stream(after) != hipSuccess) return fail(SRCNN_E_HIP, "stream failed before a device-to-host copy");
+    HostBounce& b = cx.bounce;
+    std::lock_guard<std::mutex> lk(b.mu);
+    if (int rc = bounce_ready(cx, b)) return rc;
+    unsigned char* dst = static_cast<unsigned char*>(h_dst);
+    const unsigned char* src = static_cast<const unsigned char*>(d_src);
+    // chunk i+1 is on the copy engine while chunk i is copied out of its slot
+    const size_t nchunks = (bytes + HostBounce::kSlot - 1) / HostBounce::kSlot;
+    auto queue = [&](size_t i) -> int {
+        const int k = (int)(i & 1);
+        const size_t off = i * HostBounce::kSlot, len = std::min(HostBounce::kSlot, bytes - off);
+        HIP_TRY(hipMemcpyAsync(b.pin + k * HostBounce::kSlot, src + off, len, hipMemcpyDeviceToHost, b.st));
+        HIP_TRY(hipEventRecord(b.ev[k], b.st));
+        return SRCNN_OK;
+    };
+    if (int rc = queue(0)) return rc;
+    for (size_t i = 0; i < nchunks; ++i) {
+        const int k = (int)(i & 1);
+        const size_t off = i * HostBounce::kSlot, len = std::min(HostBounce::kSlot, bytes - off);
+        if (wait_event(b.ev[k]) != hipSuccess) return fail(SRCNN_E_HIP, "bounced D2H copy failed");
+        if (i + 1 < nchunks) { if (int rc = queue(i + 1)) return rc; }
+        parallel_memcpy(dst + off, b.pin + k * HostBounce::kSlot, len);
+    }
+    return SRCNN_OK;
 }
 
 int grow_pinned(Ctx& cx, unsigned char*& p, size_t& have, size_t want)
@@ -1048,6 +1139,8 @@ void release_context(Ctx& cx)
     cx.fused_w = nullptr;
     (void)hipFree(cx.clock_buf);
     cx.clock_buf = nullptr;
+    { std::lock_guard<std::mutex> bl(cx.bounce.mu); cx.bounce.release(); }
+    { std::lock_guard<std::mutex> hl(cx.host_call.mu); cx.host_call.release(); }
 }
 
 }  // namespace
@@ -1158,6 +1251,16 @@ int srcnn_trim(void)
             for (auto& l : cx->lanes)
                 if (!l->busy) { (void)hipStreamSynchronize(l->st); (void)hipStreamSynchronize(l->copy_st); l->release_buffers(); }
         }
+        {
+            std::lock_guard<std::mutex> bl(cx->bounce.mu);
+            if (cx->bounce.st) (void)hipStreamSynchronize(cx->bounce.st);
+            cx->bounce.release();
+        }
+        {
+            std::lock_guard<std::mutex> hl(cx->host_call.mu);      // (a convenience call in flight holds it: trim waits for it)
+            (void)hipDeviceSynchronize();
+            cx->host_call.release();
+        }
         std::lock_guard<std::mutex> lk(cx->mu);
         bool any = false;
         for (auto it = cx->tables.begin(); it != cx->tables.end();) {
@@ -1234,17 +1337,17 @@ void srcnn_host_free_pinned(void* p)
 
 int srcnn_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 {
-    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
-    if (stream) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
-    else HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
-    return SRCNN_OK;
+    Ctx* cx = ctx_for_stream(stream);
+    if (!cx) return SRCNN_E_NODEVICE;
+    if (int rc = bind(*cx)) return rc;
+    return copy_h2d_any(*cx, dst, src, bytes, (hipStream_t)stream);
 }
 int srcnn_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
 {
-    if (!ctx_for_stream(stream)) return SRCNN_E_NODEVICE;
-    if (stream) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    else HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-    return SRCNN_OK;
+    Ctx* cx = ctx_for_stream(stream);
+    if (!cx) return SRCNN_E_NODEVICE;
+    if (int rc = bind(*cx)) return rc;
+    return copy_d2h_any(*cx, dst, src, bytes, (hipStream_t)stream);
 }
 int srcnn_memset_dev(void* dst, int byte, size_t bytes, void* stream)
 {

@@ -56,6 +56,9 @@ std::vector<hipEvent_t> g_events;       // sub-band "kernels queued" events + on
 std::mutex g_mu;
 std::vector<unsigned long long> g_verified;   // checksums of the tables every rank was seen to agree on (bounded)
 unsigned long long* g_check = nullptr;  // SRCNN_COMM_CHECK: two device words for the min/max all-reduce of a table's checksum
+unsigned long long* g_check_host = nullptr;   // ... and their page-locked staging (lives as long as the communicator: a copy queued from it
+                                              //     can never outlive its source, as one from a stack array could on an early return)
+std::mutex g_check_mu;                        // one verification at a time (the words are shared)
 std::atomic<bool> g_poisoned{false};    // a deadline was missed: the communicator was aborted, every later call fails at once
 
 // ---- deadlines -------------------------------------------------------------------------------------------------------
@@ -282,6 +285,7 @@ int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int n
         return SRCNN_E_DEVMEM;
     }
     if (hipMalloc((void**)&g_check, 2 * sizeof(unsigned long long)) != hipSuccess) g_check = nullptr;    // SRCNN_COMM_CHECK only
+    if (hipHostMalloc((void**)&g_check_host, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) g_check_host = nullptr;
     {
         std::lock_guard<std::mutex> ak(g_abort_mu);
         ++g_gen;
@@ -345,6 +349,7 @@ int srcnn_comm_destroy(void)
     g_comm = nullptr;
     hipFree(g_token); g_token = nullptr;
     hipFree(g_check); g_check = nullptr;
+    if (g_check_host) { (void)hipHostFree(g_check_host); g_check_host = nullptr; }
     for (auto e : g_events) (void)hipEventDestroy(e);
     g_events.clear();
     if (g_comm_stream) (void)hipStreamDestroy(g_comm_stream);
@@ -374,16 +379,18 @@ int verify_table(const CommView& v, unsigned long long h, hipStream_t s)
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (std::find(g_verified.begin(), g_verified.end(), h) != g_verified.end()) return SRCNN_OK;
-        if (!g_check) return comm_fail("SRCNN_COMM_CHECK: no device words for the checksum");
+        if (!g_check || !g_check_host) return comm_fail("SRCNN_COMM_CHECK: no words for the checksum");
     }
-    unsigned long long words[2] = {h, ~h};                   // min(h) and min(~h) = ~max(h)
-    if (hipMemcpyAsync(g_check, words, sizeof words, hipMemcpyHostToDevice, s) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: upload failed");
+    std::lock_guard<std::mutex> one(g_check_mu);
+    unsigned long long* words = g_check_host;
+    words[0] = h; words[1] = ~h;                             // min(h) and min(~h) = ~max(h)
+    if (hipMemcpyAsync(g_check, words, 2 * sizeof *words, hipMemcpyHostToDevice, s) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: upload failed");
     const bool armed = watchdog().arm(v.comm, v.gen);
     const ncclResult_t r = R.AllReduce(g_check, g_check, 2, ncclUint64, ncclMin, v.comm, s);
     const bool late = watchdog().disarm(armed);
     if (late || r != ncclSuccess) return comm_fail(late ? "SRCNN_COMM_CHECK: all-reduce missed its deadline" : "SRCNN_COMM_CHECK: all-reduce failed");
     if (wait_stream_deadline(s, v.comm, v.gen) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: a rank never arrived (deadline)");
-    if (hipMemcpy(words, g_check, sizeof words, hipMemcpyDeviceToHost) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: read-back failed");
+    if (hipMemcpy(words, g_check, 2 * sizeof *words, hipMemcpyDeviceToHost) != hipSuccess) return comm_fail("SRCNN_COMM_CHECK: read-back failed");
     if (words[0] != ~words[1]) {
         snprintf(g_cerr, sizeof g_cerr, "SRCNN_COMM_CHECK: the ranks disagree about the gather table (this rank %016llx, min %016llx, max %016llx)",
                  h, words[0], ~words[1]);

@@ -157,6 +157,29 @@ struct NodeLane {
     void release();
 };
 
+// Pageable host memory never goes to a HIP copy.  Above 128 KB the runtime pins the caller's pages IN PLACE for the transfer
+// (a userptr mapping, 32 MB at a time); when the range lies in the malloc heap and the C library trims that heap -- any free()
+// on any thread can -- the mapping is invalidated under the copy engine and the process dies with "Memory access fault by GPU
+// ... on address <a heap address>" (round 6: the GPU suite, 4 runs of 4, until MALLOC_TRIM_THRESHOLD_ was raised).  So every
+// copy between the device and memory the library did not page-lock itself bounces through these two page-locked slots:
+// memcpy + DMA, double-buffered, at memcpy speed -- which is what the runtime's own staging path costs too.
+struct HostBounce {
+    std::mutex mu;                      // one bounced copy at a time per context
+    unsigned char* pin = nullptr;       // 2 slots of kSlot bytes, allocated on first use
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    static constexpr size_t kSlot = 16u << 20;
+    void release();
+};
+// device buffers of the host-pointer convenience calls (srcnn_y_path_f32 and what is built on it): grow-only; a call holds
+// `mu` from its H2D to its D2H, so such calls are serialised per context (they shared the NULL stream before as well)
+struct HostCallBuffers {
+    std::mutex mu;
+    float* d_in = nullptr;  size_t d_in_n = 0;
+    float* d_out = nullptr; size_t d_out_n = 0;
+    void release() { (void)hipFree(d_in); (void)hipFree(d_out); d_in = d_out = nullptr; d_in_n = d_out_n = 0; }
+};
+
 struct Ctx {
     int index = 0;          // position in Global::ctxs
     int device = 0;         // physical HIP device
@@ -180,6 +203,8 @@ struct Ctx {
     std::vector<std::unique_ptr<ProcLane>> lanes;
     std::mutex node_mu;                 // the node-level tiled frame is serialised per context
     NodeLane node;
+    HostBounce bounce;
+    HostCallBuffers host_call;
 };
 
 struct Global {
@@ -250,6 +275,12 @@ Workspace* workspace_for(Ctx& cx, hipStream_t s);
 void* pinned_alloc(Ctx& cx, size_t bytes);      // page-locked, visible to every device, on the context's NUMA node
 int grow_pinned(Ctx& cx, unsigned char*& p, size_t& have, size_t want);
 bool pinned_by_library(const void* p, size_t n);   // [p, p+n) lies inside a block from srcnn_host_alloc_pinned
+bool host_is_page_locked(const void* p);           // hipHostMalloc / hipHostRegister memory (asks the runtime)
+// Blocking copies between device memory and ANY host memory (see HostBounce): page-locked host memory goes straight to the copy
+// engine, everything else through the context's bounce slots.  `after` (may be NULL): work already queued on that stream
+// is finished first, so the call is ordered on it like the hipMemcpyAsync it replaces.
+int copy_h2d_any(Ctx& cx, void* d_dst, const void* h_src, size_t bytes, hipStream_t after);
+int copy_d2h_any(Ctx& cx, void* h_dst, const void* d_src, size_t bytes, hipStream_t after);
 
 // ---- the path (srcnn_capi.cpp) ----
 int check_plane(const void* in, unsigned w, unsigned h, const void* out);

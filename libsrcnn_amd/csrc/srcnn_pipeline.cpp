@@ -117,7 +117,8 @@ bool try_thread(std::thread& t, F&& f)
 // ------------------------------------------------------------------------------------------------------------------
 // Frame stream on ONE context.  in/out are already page-locked (or pageable: the copies then just do not overlap).
 // ------------------------------------------------------------------------------------------------------------------
-int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph, int mode)
+int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph, int mode,
+                  bool in_locked, bool out_locked)
 {
     int rc = bind(cx);
     if (rc) return rc;
@@ -154,8 +155,10 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
     std::mutex capture_mu; // the copier's event queries stay out of the kernel stream's graph captures
     auto copy_frame = [&](unsigned f) {
         StreamSlot& sl = cx.slots[f % nslots];
+        // (a buffer that could not be page-locked is never handed to the runtime as it is: HostBounce)
         if (wait_event(sl.e_k, &capture_mu) != hipSuccess ||
-            hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.cst) != hipSuccess ||
+            (out_locked ? hipMemcpyAsync(out + f * out_n, sl.dout, out_b, hipMemcpyDeviceToHost, sl.cst) != hipSuccess
+                        : copy_d2h_any(cx, out + f * out_n, sl.dout, out_b, sl.cst) != SRCNN_OK) ||
             hipEventRecord(sl.e_out, sl.cst) != hipSuccess) copy_err = 1;
         copied.publish(f + 1);
     };
@@ -200,7 +203,8 @@ int stream_on_ctx(Ctx& cx, const float* in, unsigned w, unsigned h, unsigned nfr
             if (wait_event(sl.e_out) != hipSuccess) { rc = fail(SRCNN_E_HIP, "D2H"); break; }
         }
         // frame in: also resolved on the host (the previous frame's kernels keep the device busy meanwhile)
-        if (hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.cst) != hipSuccess ||
+        if ((in_locked ? hipMemcpyAsync(sl.din, in + f * in_n, in_b, hipMemcpyHostToDevice, sl.cst) != hipSuccess
+                       : copy_h2d_any(cx, sl.din, in + f * in_n, in_b, sl.cst) != SRCNN_OK) ||
             hipEventRecord(sl.e_in, sl.cst) != hipSuccess || wait_event(sl.e_in) != hipSuccess) {
             rc = fail(SRCNN_E_HIP, "H2D"); break;
         }
@@ -466,7 +470,7 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if (upto == staged) return SRCNN_OK;
         const size_t off = (size_t)staged * w * d, nbytes = (size_t)(upto - staged) * w * d;
         if (small) {
-            HIP_TRY(hipMemcpyAsync(d_rgb + off, J.rgb + off, nbytes, hipMemcpyHostToDevice, s));
+            if (int r = copy_h2d_any(cx, d_rgb + off, J.rgb + off, nbytes, s)) return r;      // (pageable: through the bounce slots)
         } else {
             // on the lane's own input stream, so that the copy runs BESIDE the previous band's kernels.  The band's kernels may
             // not start before the rows are there: this thread waits for the copy (polling; the previous band keeps the device
@@ -577,8 +581,8 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if ((rc = stage_rows(hi))) return rc;
         if ((rc = run_band(R0, R1))) return rc;
         chain_out();
-        HIP_TRY(hipMemcpyAsync(J.out + (size_t)R0 * dw * d, d_out, out_bytes, hipMemcpyDeviceToHost, s));
-        if (J.conv) HIP_TRY(hipMemcpyAsync(J.conv + (size_t)R0 * dw, d_conv, share_px, hipMemcpyDeviceToHost, s));
+        if ((rc = copy_d2h_any(cx, J.out + (size_t)R0 * dw * d, d_out, out_bytes, s))) return rc;
+        if (J.conv && (rc = copy_d2h_any(cx, J.conv + (size_t)R0 * dw, d_conv, share_px, s))) return rc;
         HIP_TRY(wait_stream(s));
         return SRCNN_OK;
     }
@@ -735,18 +739,19 @@ int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsig
     if ((rc = check_plane(in, w, h, out))) return rc;
     if (dw == 0 || dh == 0) return fail(SRCNN_E_SCALE, "scaled size %ux%u", dw, dh);
     if (!cur_ctx()) return SRCNN_E_NODEVICE;
-    float *d_in = nullptr, *d_out = nullptr;
-    const size_t in_b = sizeof(float) * (size_t)w * h, out_b = sizeof(float) * (size_t)dw * dh;
-    if (hipMalloc((void**)&d_in, in_b) != hipSuccess || hipMalloc((void**)&d_out, out_b) != hipSuccess) {
-        hipFree(d_in);
-        return fail(SRCNN_E_DEVMEM, "device allocation of %zu+%zu bytes failed", in_b, out_b);
-    }
-    rc = SRCNN_OK;
-    if (hipMemcpy(d_in, in, in_b, hipMemcpyHostToDevice) != hipSuccess) rc = fail(SRCNN_E_HIP, "H2D copy failed");
-    if (!rc) rc = srcnn_y_path_f32_dev(d_in, w, h, dw, dh, filter, d_out, nullptr);
-    if (!rc && hipMemcpy(out, d_out, out_b, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SRCNN_E_HIP, "D2H copy failed");
-    hipFree(d_in); hipFree(d_out);
-    return rc;
+    // Device buffers kept per context (grow-only; srcnn_trim gives them back), copies through copy_*_any: neither a
+    // hipMalloc / hipFree pair per call (a device-wide sync each) nor a pageable pointer handed to the runtime (HostBounce).
+    Ctx& cx = *cur_ctx();
+    if ((rc = bind(cx))) return rc;
+    const size_t in_n = (size_t)w * h, out_n = (size_t)dw * dh;
+    HostCallBuffers& hb = cx.host_call;
+    std::lock_guard<std::mutex> one(hb.mu);
+    if ((rc = grow(hb.d_in, hb.d_in_n, in_n))) return rc;
+    if ((rc = grow(hb.d_out, hb.d_out_n, out_n))) return rc;
+    if ((rc = copy_h2d_any(cx, hb.d_in, in, sizeof(float) * in_n, nullptr))) return rc;
+    if ((rc = srcnn_y_path_f32_dev(hb.d_in, w, h, dw, dh, filter, hb.d_out, nullptr))) return rc;
+    if (wait_stream(nullptr) != hipSuccess) return fail(SRCNN_E_HIP, "the path failed on the device");
+    return copy_d2h_any(cx, out, hb.d_out, sizeof(float) * out_n, nullptr);
 }
 
 int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out)
@@ -768,15 +773,17 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
 
     // page-lock the caller's frames so the copies are truly asynchronous -- unless they already are (buffers from
     // srcnn_host_alloc_pinned / hipHostMalloc: registering a gigabyte again costs milliseconds per call); harmless if it fails
-    const bool reg_in = !is_pinned(in) && hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterPortable) == hipSuccess;
-    const bool reg_out = !is_pinned(out) && hipHostRegister(out, out_b * nframes, hipHostRegisterPortable) == hipSuccess;
+    const bool pin_in = is_pinned(in), pin_out = is_pinned(out);
+    const bool reg_in = !pin_in && hipHostRegister(const_cast<float*>(in), in_b * nframes, hipHostRegisterPortable) == hipSuccess;
+    const bool reg_out = !pin_out && hipHostRegister(out, out_b * nframes, hipHostRegisterPortable) == hipSuccess;
     (void)hipGetLastError();
+    const bool in_locked = pin_in || reg_in, out_locked = pin_out || reg_out;
 
     // Frames are independent: with several contexts they are dealt out in contiguous chunks, one worker per context
     // (no data-path exchange at all; each context runs its own two-slot pipeline).
     const unsigned nctx = (unsigned)std::min<unsigned>((unsigned)context_count(), nframes);
     if (nctx <= 1) {
-        rc = stream_on_ctx(*cur, in, w, h, nframes, out, use_graph, mode);
+        rc = stream_on_ctx(*cur, in, w, h, nframes, out, use_graph, mode, in_locked, out_locked);
     } else {
         std::vector<int> rcs(nctx, SRCNN_OK);
         std::vector<std::string> errs(nctx);
@@ -784,7 +791,7 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
         auto work = [&](unsigned k) {
             const unsigned f0 = (unsigned)((unsigned long long)nframes * k / nctx), f1 = (unsigned)((unsigned long long)nframes * (k + 1) / nctx);
             Ctx* cx = context_at((int)k);
-            rcs[k] = cx ? stream_on_ctx(*cx, in + f0 * in_n, w, h, f1 - f0, out + f0 * out_n, use_graph, mode) : SRCNN_E_NODEVICE;
+            rcs[k] = cx ? stream_on_ctx(*cx, in + f0 * in_n, w, h, f1 - f0, out + f0 * out_n, use_graph, mode, in_locked, out_locked) : SRCNN_E_NODEVICE;
             if (rcs[k]) errs[k] = srcnn_last_error();
         };
         std::vector<bool> started(nctx, false);
