@@ -119,9 +119,13 @@ def lib():
             "srcnn_fused_diag": (i, [vp, u, u, vp, vp, vp]),
             "srcnn_debug_clock_probe": (i, [i]), "srcnn_debug_clock_read": (i, [i, vp, vp, i]),
             "srcnn_debug_settings": (i, [C.c_char_p, sz, i]),
+            "srcnn_debug_process_phases": (i, [C.POINTER(C.c_double), i]),
+            "srcnn_debug_stream_mode": (i, [C.POINTER(u), C.POINTER(u), C.POINTER(i)]),
             "srcnn_comm_barrier": (i, [vp]), "srcnn_comm_wait": (i, [vp]), "srcnn_comm_set_timeout_ms": (i, [i]),
         }
         for name, (res, args) in sig.items():
+            if name in DEBUG_SYMBOLS and not hasattr(L, name) and os.environ.get("SRCNN_AMD_LIB"):
+                continue                  # an older build loaded for an A/B run (tools/lib_ab.py): it may lack newer instruments
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         cfg = getattr(L, CXX_SYMBOLS[0])

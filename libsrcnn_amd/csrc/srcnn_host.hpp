@@ -166,7 +166,6 @@ struct NodeLane {
 struct HostBounce {
     std::mutex mu;                      // one bounced copy at a time per context
     unsigned char* pin = nullptr;       // 2 slots of kSlot bytes, allocated on first use
-    hipStream_t st = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     static constexpr size_t kSlot = 16u << 20;
     void release();

@@ -750,8 +750,7 @@ int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsig
     if ((rc = grow(hb.d_out, hb.d_out_n, out_n))) return rc;
     if ((rc = copy_h2d_any(cx, hb.d_in, in, sizeof(float) * in_n, nullptr))) return rc;
     if ((rc = srcnn_y_path_f32_dev(hb.d_in, w, h, dw, dh, filter, hb.d_out, nullptr))) return rc;
-    if (wait_stream(nullptr) != hipSuccess) return fail(SRCNN_E_HIP, "the path failed on the device");
-    return copy_d2h_any(cx, out, hb.d_out, sizeof(float) * out_n, nullptr);
+    return copy_d2h_any(cx, out, hb.d_out, sizeof(float) * out_n, nullptr);       // same (default) stream: ordered behind the kernels
 }
 
 int srcnn_y_upscale2x_f32(const float* in, unsigned w, unsigned h, float* out)
@@ -778,6 +777,10 @@ int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsign
     const bool reg_out = !pin_out && hipHostRegister(out, out_b * nframes, hipHostRegisterPortable) == hipSuccess;
     (void)hipGetLastError();
     const bool in_locked = pin_in || reg_in, out_locked = pin_out || reg_out;
+    if (settings().trace)
+        fprintf(stderr, "srcnn_y_upscale2x_f32_stream %ux%u x %u frames, use_graph %d: source %s, result %s\n", w, h, nframes, use_graph,
+                pin_in ? "page-locked" : reg_in ? "page-locked for this call" : "pageable (bounced)",
+                pin_out ? "page-locked" : reg_out ? "page-locked for this call" : "pageable (bounced)");
 
     // Frames are independent: with several contexts they are dealt out in contiguous chunks, one worker per context
     // (no data-path exchange at all; each context runs its own two-slot pipeline).
