@@ -387,7 +387,8 @@ def baseline_configs(S):
 
 def roofline_all(stage_ms, n_out, in_px):
     """Every kernel of the strict path against ITS OWN bound: achieved, the peak or floor it is held to,
-    and the fraction.  stage_ms = average launch duration per 4K -> 8K frame from the HIP events of the timed region."""
+    and the fraction.  stage_ms = device time per 4K -> 8K frame (all of its launches: a frame is two bands under the default scratch cap) from the HIP
+    events of the timed region."""
     CLK = 2.4e9
     SIMDS = 256 * 4
     rows = []
@@ -397,7 +398,7 @@ def roofline_all(stage_ms, n_out, in_px):
         # strict tap-step floor measured by tools/ubench/occupancy_tapstep.hip: 70 cycles per 1024 MAC and SIMD
         floor_ms = (MAC_L12 * n_out / 1024.0) * 70.0 / SIMDS / CLK * 1e3
         rows.append({"kernel": "k_conv12_mfma", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tf / PEAK_F32_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+                     "frac": round(tf / PEAK_F32_TFLOPS, 4), "ms_per_frame": round(ms, 4),
                      "own_floor": {"what": "no-FMA ceiling (product and sum rounded separately): 0.5 of peak; measured floor of the "
                                            "MFMA-product + VALU-sum step: 70 cycles per 1024 MAC per SIMD at 2.4 GHz "
                                            "(profiles/r06_occupancy_tapstep.txt)",
@@ -410,7 +411,7 @@ def roofline_all(stage_ms, n_out, in_px):
         # 4.14 cycles per instruction of the same mix in a register-only stream (profiles/r03_valu_rates.txt, "conv3 pair")
         floor_ms = (n_out / 256.0) * 32 * 254 * 4.14 / SIMDS / CLK * 1e3
         rows.append({"kernel": "k_conv3", "bound": "valu", "achieved": round(tf, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tf / PEAK_F32_TFLOPS, 4), "avg_launch_ms": round(ms, 4),
+                     "frac": round(tf / PEAK_F32_TFLOPS, 4), "ms_per_frame": round(ms, 4),
                      "own_floor": {"what": "fp64-rate VALU issue: per MAC one half v_pk_mul_f32, one v_cvt_f64_f32 and one v_add_f64 "
                                            "(the reference rounds the product to fp32, then sums in fp64); 254 instructions per wave "
                                            "and channel at the mix's measured 4.14 cycles each (profiles/r03_valu_rates.txt), 2.4 GHz",
@@ -420,7 +421,7 @@ def roofline_all(stage_ms, n_out, in_px):
         nbytes = 4.0 * in_px + 4.0 * n_out
         gbs = nbytes / (ms * 1e-3) / 1e9
         rows.append({"kernel": "k_rs2d_dma", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(ms, 4),
+                     "frac": round(gbs / PEAK_HBM_GBS, 4), "ms_per_frame": round(ms, 4),
                      "own_floor": {"what": "algorithmic bytes: fp32 source plane in + fp32 2x plane out", "bytes_per_launch": nbytes,
                                    "floor_ms": round(nbytes / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
                                    "frac_of_floor": round(nbytes / (PEAK_HBM_GBS * 1e9) * 1e3 / ms, 4)}})
@@ -941,11 +942,17 @@ def main():
         value = mpix_step / (ms_per_step * 1e-3)
         c12_ms, c12_n = prof["conv12"]
         avg12 = c12_ms / max(c12_n, 1)
-        flops12 = 2.0 * MAC_L12 * n_out                         # algorithmic FLOPs of one conv12 launch (one frame)
+        frames_timed = F * args.steps                            # frames this rank pushed through the timed region
+        # One launch of the layer kernels = one BAND of a frame: a 7680x4320 frame holds 4.25 GB of layer-2 planes and the default
+        # scratch cap (SRCNN_MAX_WORKSPACE_MB = 2048) makes it two bands of 2160 rows.  Algorithmic work per launch = the
+        # frame's, divided by the launches per frame (recomputed halo rows are not algorithmic work).
+        launches_per_frame = max(1.0, c12_n / max(frames_timed, 1))
+        px_per_launch = n_out / launches_per_frame
+        flops12 = 2.0 * MAC_L12 * px_per_launch                 # algorithmic FLOPs of one conv12 launch
         achieved = flops12 / (avg12 * 1e-3) / 1e12 if avg12 > 0 else 0.0
         traffic, traffic_from, whole_traffic = traffic_record()
-        stage = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
-        alg_bytes12 = (4 + 128) * n_out                         # layer-1+2 kernel: fp32 Y in, 32 fp32 planes out
+        stage = {k: round(v[0] / max(frames_timed, 1), 4) for k, v in prof.items()}          # per FRAME (all its launches)
+        alg_bytes12 = (4 + 128) * px_per_launch                 # layer-1+2 kernel: fp32 Y in, 32 fp32 planes out
         out = {
             "metric": METRIC,
             "value": round(value, 2), "unit": "MPix/s",
@@ -968,6 +975,7 @@ def main():
                          "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_from": traffic_from,
                          "frac_of_no_fma_ceiling": round(achieved / (PEAK_F32_TFLOPS / 2), 4),
                          "avg_launch_ms": round(avg12, 4), "launches": int(c12_n),
+                         "launches_per_frame": round(launches_per_frame, 3), "output_px_per_launch": px_per_launch,
                          "flops_per_launch": flops12,
                          "note": "strict mode rounds product and sum separately (no FMA): ceiling is 0.5 of this peak",
                          "hbm": {"algorithmic_bytes_per_launch": alg_bytes12,

@@ -112,7 +112,9 @@ int         srcnn_set_mode(int mode);              /* SRCNN_MODE_*; returns prev
 int         srcnn_get_mode(void);
 int         srcnn_device_name(char* buf, size_t cap);
 /* Upper bound, in bytes, on the layer-2 scratch (128 B per output pixel) one pass may hold; larger frames / bands
- * are produced in horizontal sub-bands with identical results.  Default 16 GiB or env SRCNN_MAX_WORKSPACE_MB.
+ * are produced in horizontal sub-bands with identical results.  Default 2 GiB or env SRCNN_MAX_WORKSPACE_MB: a
+ * 3840x2160 -> 7680x4320 frame (4.25 GB of layer-2 planes) runs as two bands at the speed of one; down to 512 MiB banding
+ * costs < 2 %, 256 MiB +9 %, below that the short bands fill the persistent grid badly (profiles/r06_lowmem.txt).
  * Returns the previous limit.  Applies to calls that start afterwards, including the bands of srcnn_process_u8.  A band is
  * never smaller than 16 rows (one tile row of the layer kernels), so a limit below 16 rows' worth is exceeded, not refused. */
 size_t      srcnn_set_workspace_limit(size_t bytes);
@@ -145,7 +147,7 @@ int   srcnn_event_elapsed_ms(void* start, void* stop, float* ms);   /* syncs on 
  * d_out: planar float32 Y', (2w)*(2h) (device memory)
  * Launches asynchronously on `stream` (NULL = default stream); scratch comes from a grow-only
  * per-stream workspace owned by the library, so steady-state calls do no allocation.  The scratch is
- * 128 B per output pixel; above a budget (env SRCNN_MAX_WORKSPACE_MB, default 16384) the frame is
+ * 128 B per output pixel; above a budget (env SRCNN_MAX_WORKSPACE_MB, default 2048) the frame is
  * produced in horizontal bands internally, with identical results.  Limits: 2^20 output rows, 2^31 pixels. */
 int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_out, void* stream);
 
@@ -304,9 +306,15 @@ int srcnn_comm_barrier(void* stream);
  * call returns SRCNN_E_COMM, and every later srcnn_comm_* call fails at once until srcnn_comm_destroy + srcnn_comm_init.
  * Default 60000 ms, env SRCNN_COMM_TIMEOUT_MS; 0 = no deadline.  srcnn_comm_set_timeout_ms returns the previous value.
  * srcnn_comm_destroy drains what is still queued under the same deadline and aborts instead of destroying on a miss.
- * Before the first gather that uses a new counts / offsets table, a checksum of the table is all-reduced (16 bytes), so that
- * ranks which disagree return SRCNN_E_COMM together instead of pairing a send with the wrong receive (SRCNN_COMM_CHECK=0
- * skips it).  The tables the library derives itself depend on (width, height, ranks, pieces) only -- never on a switch. */
+ * The first time a rank uses a counts / offsets table, a checksum of the table is all-reduced (16 bytes, the host waits for
+ * it: do not make that first call inside a stream capture), so that ranks which disagree FROM THE START return SRCNN_E_COMM
+ * together, in milliseconds, instead of pairing a send with the wrong receive (SRCNN_COMM_CHECK=0 skips it).  A rank verifies
+ * a table once; ranks that agreed on one table and disagree later (one still has its table verified, the other arrives with
+ * a new one) cannot be paired by the check and are caught by the deadline instead: every rank returns SRCNN_E_COMM after
+ * SRCNN_COMM_TIMEOUT_MS, the communicator is aborted.  The tables the library derives itself depend on (width, height, ranks,
+ * pieces) only -- never on a switch.
+ * srcnn_comm_destroy drains the NULL stream, the streams made by srcnn_stream_create and the library's own comm stream under
+ * the deadline; communication queued on a raw HIP stream of the caller's must be synchronised by the caller first. */
 int srcnn_comm_wait(void* stream);
 int srcnn_comm_set_timeout_ms(int ms);
 

@@ -92,7 +92,9 @@ void abort_comm(ncclComm_t comm, unsigned gen)
 
 // (csrc/srcnn_watchdog.hpp: HIP-free, so the same class runs under ThreadSanitizer in tests/host/)
 struct CommWatchdog {
-    srcnn::Watchdog w{[](unsigned gen) { if (gen == g_gen.load()) g_poisoned = true; },
+    // (the mark is made under g_abort_mu like the abort itself: a destroy + init between the generation check and the store
+    //  would otherwise leave the NEW communicator poisoned with g_abort_called still false -- ADVICE r5)
+    srcnn::Watchdog w{[](unsigned gen) { std::lock_guard<std::mutex> lk(g_abort_mu); if (gen == g_gen.load()) g_poisoned = true; },
                       [](void* comm, unsigned gen) { abort_comm(static_cast<ncclComm_t>(comm), gen); }};
     bool arm(ncclComm_t comm, unsigned gen) { return w.arm(comm, gen, g_timeout_ms.load()); }
     bool disarm(bool armed) { return w.disarm(armed); }
@@ -228,6 +230,10 @@ unsigned long long fnv1a(const void* p, size_t n, unsigned long long h = 1469598
 
 namespace srcnn {
 constexpr int kTiledPlanGrid = 512, kTiledPlanTileRows = 16;
+// ... written down as constants ON PURPOSE (ranks with different switches must derive the same table), but tied to the kernel's
+// geometry at compile time: a change of the layer-1+2 tile or of its workgroups per CU has to be made here as well
+static_assert(kTiledPlanTileRows == srcnn::kConv12TileRows && kTiledPlanGrid == srcnn::kConv12BlocksPerCU * 256,
+              "the tiled band plan assumes the production layer-1+2 geometry on a 256-CU device");
 std::vector<unsigned> tiled_cuts(unsigned out_w, unsigned out_h, int rank, int nranks, int npieces)
 {
     unsigned b0 = 0, bn = 0;

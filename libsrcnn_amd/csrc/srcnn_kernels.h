@@ -115,6 +115,9 @@ void launch_conv12_mfma(const float* Y, int W, int H, int y_row_base, int y_rows
                         int out_rows, int relax, int num_cus, hipStream_t s, unsigned long long* clk = nullptr,
                         unsigned* queue = nullptr);
 void conv12_grid_info(int num_cus, int* blocks, int* tile_rows);
+// the same two numbers at compile time (srcnn_kernels.hip static_asserts them against M_TH / M_BPC): tile height and resident
+// workgroups per CU of the layer-1+2 kernel
+constexpr int kConv12TileRows = 16, kConv12BlocksPerCU = 2;
 // relax: RELAX_L3_X64 / RELAX_L3_F32 bits (neither = strict)
 void launch_conv3(const float* C2, size_t plane_stride, int W, int H, int c2_row_base, int c2_rows, float* out,
                   int out_row0, int out_rows, int relax, hipStream_t s);

@@ -611,6 +611,7 @@ constexpr int M_W1 = 81 * 64, M_W2 = 32 * 64, M_B1 = 64, M_B2 = 32;
 constexpr int M_C1 = 32 * 32;                      // per-wave layer-1 slab: 32 channels x 32 px (one MFMA block at a time)
 constexpr int M_YT = (M_TH + 8) * M_LW;            // one Y tile with its 4-sample halo
 constexpr int M_BPC = 2;                           // resident workgroups per CU
+static_assert(M_TH == kConv12TileRows && M_BPC == kConv12BlocksPerCU, "srcnn_kernels.h carries this geometry for the band planners");
 constexpr int m_ybufs(bool ld) { return ld ? 2 : 1; }          // LDS-DMA staging double-buffers the Y tile
 constexpr int m_lds_floats(bool ld) { return M_W1 + M_W2 + M_B1 + M_B2 + m_ybufs(ld) * M_YT + M_NW * M_C1 + 2; }   // + the two tile-queue slots
 

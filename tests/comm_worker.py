@@ -125,6 +125,29 @@ def cmd_mismatch(rank, world, args):
             "check": os.environ.get("SRCNN_COMM_CHECK", "")}
 
 
+def cmd_mismatch_later(rank, world, args):
+    """every rank first agrees on table T1 (verified, cached); then the last rank alone comes with another table.
+    The ranks that have T1 cached go straight to their send / receive while the last one all-reduces its new checksum: no
+    pairing is possible, and what must happen is the DEADLINE -- every rank returns SRCNN_E_COMM after SRCNN_COMM_TIMEOUT_MS
+    (set short by the test), the communicator is aborted, and destroy comes back."""
+    L = S.lib()
+    w, h = 640, 400
+    d_in = S.DeviceBuffer.from_numpy(synth.plane(h, w, 3, "noise"))
+    t = multigpu.TiledFrameGPU(w, h, rank, world, nsub=4)
+    rc1 = L.srcnn_comm_tiled_y_upscale2x_f32_dev(d_in.ptr, w, h, t.d_band.ptr, t.d_full.ptr if t.d_full else None, 0, 4, None)
+    rc1w = L.srcnn_comm_wait(None)
+    nsub = 3 if rank == world - 1 else 4
+    t0 = time.perf_counter()
+    rc2 = L.srcnn_comm_tiled_y_upscale2x_f32_dev(d_in.ptr, w, h, t.d_band.ptr, t.d_full.ptr if t.d_full else None, 0, nsub, None)
+    rc2w = L.srcnn_comm_wait(None) if rc2 == 0 else rc2
+    ms = round((time.perf_counter() - t0) * 1e3, 1)
+    e = err()
+    t1 = time.perf_counter()
+    rc_destroy = L.srcnn_comm_destroy()
+    return {"rank": rank, "rc1": rc1, "rc1w": rc1w, "rc2": rc2, "rc2w": rc2w, "error": e, "ms": ms, "rc_destroy": rc_destroy,
+            "destroy_ms": round((time.perf_counter() - t1) * 1e3, 1)}
+
+
 def cmd_missing(rank, world, args):
     """The last rank never makes the call (it sleeps, then leaves).  Every other rank must come back with SRCNN_E_COMM once
     the deadline (SRCNN_COMM_TIMEOUT_MS, set short by the test) has passed -- and be able to destroy the communicator."""

@@ -92,6 +92,18 @@ def test_ranks_that_disagree_about_the_table_fail_fast_together():
     assert all(o["check"] == "" for o in outs)                  # ... with no switch set: it is the default
 
 
+def test_a_rank_that_disagrees_after_an_agreed_table_trips_the_deadline():
+    """The checksum is exchanged the first time a rank SEES a table, so ranks whose caches differ cannot be paired: one goes
+    to its send / receive, the other to the all-reduce.  That case ends at the deadline -- on every rank, with the communicator
+    aborted and destroy coming back -- which is what include/srcnn_amd.h promises for it."""
+    outs = run_ranks("mismatch_later", 2, env={"SRCNN_COMM_TIMEOUT_MS": "2000"})
+    for o in outs:
+        assert o["rc1"] == 0 and o["rc1w"] == 0, o              # the agreed table went through
+        assert o["rc2"] == -204 or o["rc2w"] == -204, o
+        assert 1000 < o["ms"] < 30000, o                         # the deadline, not a hang
+        assert o["destroy_ms"] < 30000, o
+
+
 def test_a_missing_rank_trips_the_deadline():
     outs = run_ranks("missing", 3, [6.0], env={"SRCNN_COMM_TIMEOUT_MS": "1500"})
     live = [o for o in outs if not o.get("absent")]

@@ -22,7 +22,9 @@ SRC = os.path.join(HERE, "fused_strict.hip")
 
 def build():
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+        import shutil
+        hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
                                "-shared", SRC, "-o", LIB])
     return C.CDLL(LIB)
 
