@@ -815,7 +815,7 @@ def traffic_record():
     figure is held to its own fingerprint."""
     from libsrcnn_amd import build as _b
     now = _b.kernel_source_sha("k_conv12_mfma")
-    for name in ("r05_pmc_conv12.json", "r04_pmc_conv12.json", "r03_pmc_conv12.json", "r02_pmc_conv12.json", "pmc_conv12.json"):
+    for name in ("r06_pmc_conv12.json", "r05_pmc_conv12.json", "r04_pmc_conv12.json", "r03_pmc_conv12.json", "r02_pmc_conv12.json", "pmc_conv12.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:

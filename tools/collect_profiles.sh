@@ -5,7 +5,7 @@
 # domains) for the strict path and for the fused non-parity tier.  tools/summarize_profiles.py then turns them into
 # profiles/<tag>_*.   The program after "--" is python3 itself (no env/bash hop: the profiler initialises the GPU).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG

@@ -52,7 +52,7 @@ def short(name):
 
 
 lines = ["# rocprofv3 summary `%s` (MI355X, `python3 bench.py`, strict mode, 3840x2160 -> 7680x4320 frames)\n" % tag]
-for sub, title in (("kt", "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras` (strict headline; every launch is one 3840x2160 frame)"), ("kt_f16", "`bench.py --tier fast_f16` (non-parity fused kernel)")):
+for sub, title in (("kt", "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras` (strict headline; every launch of a layer kernel is one band of a 3840x2160 -> 7680x4320 frame: two per frame under the default scratch cap)"), ("kt_f16", "`bench.py --tier fast_f16` (non-parity fused kernel)")):
     stats = one(sub + "/**/*_kernel_stats.csv")
     if not stats:
         continue
@@ -64,6 +64,7 @@ for sub, title in (("kt", "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no
         lines.append("| %s | %s | %.4f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
                                                        float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 pmc = {}
+pmc_n = {}
 for which in ("fetch", "write", "sq", "sq2"):
     for tier in ("strict", "fast_f16"):
         f = one("pmc_%s_%s/**/*_counter_collection.csv" % (which, tier))
@@ -75,8 +76,11 @@ for which in ("fetch", "write", "sq", "sq2"):
             agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             pmc.setdefault(k, {})[c] = sum(v) / len(v)
+            pmc_n.setdefault(k, {})[c] = len(v)          # the PMC runs push ONE frame through: launches counted = launches per frame
 if pmc:
-    lines.append("\n## PMC, one 3840x2160 frame per launch (separate passes; FETCH_SIZE/WRITE_SIZE are in KiB)\n")
+    lines.append("\n## PMC, per LAUNCH, of one 3840x2160 -> 7680x4320 frame (separate passes; FETCH_SIZE/WRITE_SIZE are in KiB).  A launch of the "
+                 "layer kernels is one band of the frame: launches per frame = " +
+                 ", ".join("%s %d" % (k.split(" ")[0], n.get("FETCH_SIZE", 0)) for k, n in pmc_n.items() if "strict" in k or "rs2d_dma" in k) + "\n")
     cols = sorted({c for v in pmc.values() for c in v})
     lines.append("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
     for k, v in pmc.items():
@@ -84,23 +88,28 @@ if pmc:
     k12 = pmc.get("k_conv12_mfma [strict]")
     if k12 and "FETCH_SIZE" in k12 and "WRITE_SIZE" in k12:
         n_out = 7680 * 4320
-        fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024
+        lpf12 = max(1, pmc_n["k_conv12_mfma [strict]"].get("FETCH_SIZE", 1))          # launches (bands) per frame
+        fetch, write = k12["FETCH_SIZE"] * 1024, k12["WRITE_SIZE"] * 1024              # per launch
         sys.path.insert(0, ROOT)
         from libsrcnn_amd import build as _b
         rec = {"kernel": "k_conv12_mfma", "tag": tag, "kernel_source_sha256": _b.kernel_source_sha("k_conv12_mfma"), "measured_at": "tools/collect_profiles.sh %s, code at commit %s" % (tag, head),
                "fetch_bytes": fetch, "write_bytes": write,
-               "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 132 * n_out,
+               "launches_per_frame": lpf12,
+               "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 132 * n_out / lpf12,
                "note": "FETCH_SIZE/WRITE_SIZE are KiB, separate passes.  The guide's x2 FETCH correction is for 16 B/lane streams; "
                        "our loads are 4 B/lane, calibrated on k_conv3 of the same run: it requests 5.65 GB (4.25 GB of unique "
                        "layer-2 planes x 1.33 halo) and FETCH_SIZE reads 4.73 GB -- a halved counter would imply 9.5 GB, more "
                        "than was requested -- so FETCH_SIZE is taken at face value.  WRITE_SIZE matches 128 B/px exactly."}
         # the other kernels of the strict path, same passes: what one 4K -> 8K frame moves through HBM in total
-        path = {"k_conv12_mfma": {"fetch_bytes": fetch, "write_bytes": write, "kernel_source_sha256": rec["kernel_source_sha256"]}}
+        # (per FRAME: per-launch average x launches per frame)
+        path = {"k_conv12_mfma": {"fetch_bytes": fetch * lpf12, "write_bytes": write * lpf12, "launches_per_frame": lpf12,
+                                  "kernel_source_sha256": rec["kernel_source_sha256"]}}
         for kname, key in (("k_conv3", "k_conv3 [strict]"), ("k_rs2d_dma", "k_rs2d_dma [plane -> plane, LDS-DMA]")):
             kk = pmc.get(key)
             if kk and "FETCH_SIZE" in kk and "WRITE_SIZE" in kk:
-                path[kname] = {"fetch_bytes": kk["FETCH_SIZE"] * 1024, "write_bytes": kk["WRITE_SIZE"] * 1024,
-                               "kernel_source_sha256": _b.kernel_source_sha(kname)}
+                lpf = max(1, pmc_n[key].get("FETCH_SIZE", 1))
+                path[kname] = {"fetch_bytes": kk["FETCH_SIZE"] * 1024 * lpf, "write_bytes": kk["WRITE_SIZE"] * 1024 * lpf,
+                               "launches_per_frame": lpf, "kernel_source_sha256": _b.kernel_source_sha(kname)}
         rec["path"] = path
         if len(path) == 3:
             total = sum(v["fetch_bytes"] + v["write_bytes"] for v in path.values())
@@ -111,8 +120,8 @@ if pmc:
             lines.append("\nwhole strict path per frame: %.3f GB through HBM vs %.3f GB algorithmic (5 B/px) -> ratio %.1f"
                          % (total / 1e9, 5 * n_out / 1e9, total / (5 * n_out)))
         json.dump(rec, open(os.path.join(dst, tag + "_pmc_conv12.json"), "w"), indent=1)
-        lines.append("\nconv12 HBM traffic per launch = %.3f GB (fetch %.3f + write %.3f) vs algorithmic %.3f GB -> ratio %.3f"
-                     % ((fetch + write) / 1e9, fetch / 1e9, write / 1e9, 132 * n_out / 1e9, (fetch + write) / (132 * n_out)))
+        lines.append("\nconv12 HBM traffic per launch (%d per frame) = %.3f GB (fetch %.3f + write %.3f) vs algorithmic %.3f GB -> ratio %.3f"
+                     % (lpf12, (fetch + write) / 1e9, fetch / 1e9, write / 1e9, 132 * n_out / lpf12 / 1e9, (fetch + write) * lpf12 / (132 * n_out)))
     kf = pmc.get("k_fused_f16 [fast tier]")
     if kf and "FETCH_SIZE" in kf and "WRITE_SIZE" in kf:
         n_out = 7680 * 4320
