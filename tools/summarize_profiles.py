@@ -37,8 +37,11 @@ def short(name):
     if "k_conv12_mfma<" in name:          # first template argument = RELAX mask: 0 strict, 3 fast tier, 1 / 2 single-layer relaxations
         r = name.split("k_conv12_mfma<")[1].split(",")[0].strip()
         return "k_conv12_mfma" + {"0": " [strict]", "3": " [fast tier]"}.get(r, " [relaxed %s]" % r)
-    if "k_conv3<" in name and name.split("k_conv3<")[1].split(">")[0].replace(" ", "").endswith(",true"):
-        return "k_conv3 [relaxed x64]"
+    if "k_conv3<" in name:              # k_conv3<STRICT, OFF64, X64, SDMA>: the third argument marks the relaxed-x64 experiment
+        targs = name.split("k_conv3<")[1].split(">")[0].replace(" ", "").split(",")
+        if len(targs) >= 3 and targs[2] == "true":
+            return "k_conv3 [relaxed x64]"
+        return "k_conv3 [strict]"
     if "k_rs2d_dma" in name:
         return "k_rs2d_dma [plane -> plane, LDS-DMA]"
     if "k_rs2d<" in name:
@@ -73,14 +76,17 @@ for which in ("fetch", "write", "sq", "sq2"):
         shutil.copy(f, os.path.join(dst, "%s_pmc_%s_%s.csv" % (tag, which, tier)))
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+            k = short(r["Kernel_Name"])
+            if tier == "fast_f16" and "fast tier" not in k:
+                k += " (in the fast_f16 run: whole frame per launch)"       # never mixed with the strict run's banded launches
+            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             pmc.setdefault(k, {})[c] = sum(v) / len(v)
             pmc_n.setdefault(k, {})[c] = len(v)          # the PMC runs push ONE frame through: launches counted = launches per frame
 if pmc:
     lines.append("\n## PMC, per LAUNCH, of one 3840x2160 -> 7680x4320 frame (separate passes; FETCH_SIZE/WRITE_SIZE are in KiB).  A launch of the "
                  "layer kernels is one band of the frame: launches per frame = " +
-                 ", ".join("%s %d" % (k.split(" ")[0], n.get("FETCH_SIZE", 0)) for k, n in pmc_n.items() if "strict" in k or "rs2d_dma" in k) + "\n")
+                 ", ".join("%s %d" % (k.split(" ")[0], n.get("FETCH_SIZE", 0)) for k, n in pmc_n.items() if ("strict" in k or "rs2d_dma" in k) and "fast_f16 run" not in k) + "\n")
     cols = sorted({c for v in pmc.values() for c in v})
     lines.append("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols))
     for k, v in pmc.items():
