@@ -608,3 +608,36 @@ def test_stream_use_graph_auto_is_cheap_in_host_cpu_by_default(srcnn):
               % ((g1, p1, fell1), cpu1 * 1e3, (g2, p2, fell2), cpu2 * 1e3, wall2 * 1e3, cpu3 * 1e3, wall3 * 1e3))
     finally:
         pin_in.free(); pin_out.free()
+
+
+@pytest.mark.gpu
+def test_pageable_host_memory_is_bounced_and_survives_heap_trims(srcnn, oracle_lib):
+    """Round 6: pageable host memory never reaches a HIP copy (the runtime pins it in place and a heap trim then invalidates the
+    mapping under the copy engine: "Memory access fault by GPU ... <heap address>", docs/HISTORY.md 11).  (a) the plumbing copies
+    round-trip pageable arrays of awkward sizes and offsets through the 16 MB bounce slots bit for bit; (b) the host-pointer call on
+    heap-resident arrays keeps working -- and stays bit-exact -- while the heap is grown, freed and trimmed between the calls."""
+    import ctypes as C
+    S = srcnn
+    rng = np.random.default_rng(606)
+    for nbytes in (1, 4097, (16 << 20) - 3, (16 << 20) + 5, (48 << 20) + 12345):
+        src = rng.integers(0, 256, nbytes + 64, dtype=np.uint8)[13:13 + nbytes]          # unaligned, pageable
+        d = S.DeviceBuffer(nbytes + 256)
+        S.check(S.lib().srcnn_memcpy_h2d(d.ptr + 128, src.ctypes.data, nbytes, None))
+        back = np.zeros(nbytes + 7, np.uint8)[7:]
+        S.check(S.lib().srcnn_memcpy_d2h(back.ctypes.data, d.ptr + 128, nbytes, None))
+        assert np.array_equal(back, src), nbytes
+        d.free()
+    libc = C.CDLL("libc.so.6")
+    libc.mallopt(-3, 64 << 20)                      # M_MMAP_THRESHOLD: arrays of a few MB come from the brk heap, as in a long-lived process
+    try:
+        y = synth.plane(300, 500, synth.SEED0 + 9, "noise")
+        want = oracle_lib.y_path(y)
+        for it in range(40):
+            ballast = [np.ones(rng.integers(1, 6) << 20, np.uint8) for _ in range(4)]      # grow the heap ...
+            yy = y.copy()                                                                  # ... a heap-resident source
+            got = S.y_upscale2x(yy)
+            assert_bit_equal(got, want, "iteration %d" % it)
+            del ballast, yy, got
+            libc.malloc_trim(0)                                                            # ... and give its top back to the system
+    finally:
+        libc.mallopt(-3, 128 << 10)
