@@ -231,7 +231,7 @@ int srcnn_y_path_f32(const float* in, unsigned w, unsigned h, unsigned dw, unsig
  * use_graph: 0 = plain launches (what a caller should ask for on ROCm 7.2: on this runtime a graph replay keeps a thread of
  * the RUNTIME spinning from launch to completion -- 9.9 ms of host CPU per 9.5 ms 4K frame against 0.6 ms, at the same
  * throughput); 1 = hipGraph replay KEPT ONLY WHILE IT IS CHEAP: the process's CPU time over the first four replayed frames is
- * held against their wall time, and above SRCNN_GRAPH_MAX_CPU_PCT (default 50 %) the graphs are retired and the stream
+ * held against their wall time, and above SRCNN_GRAPH_MAX_CPU_PCT (default 10 %: what plain launches cost) the graphs are retired and the stream
  * continues with plain launches (remembered per shape; srcnn_debug_stream_mode in srcnn_amd_debug.h says what ran);
  * 2 = hipGraph replay whatever it costs (BASELINE config "per-GPU hipGraph capture", measurements of the replay itself). */
 int srcnn_y_upscale2x_f32_stream(const float* in, unsigned w, unsigned h, unsigned nframes, float* out, int use_graph);

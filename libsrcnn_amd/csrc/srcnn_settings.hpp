@@ -24,7 +24,7 @@
     X(B, trace,            "SRCNN_TRACE",            0,     "0/1", "one stderr line per `srcnn_process_u8` share (setup / bands / stamps)") \
     X(B, roctx,            "SRCNN_ROCTX",            0,     "0/1", "roctx ranges for `rocprofv3 --marker-trace`") \
     X(S, bands,            "SRCNN_BANDS",            "",    "`f0,f1,...`", "band fractions of a large `ProcessSRCNN` image instead of the planned cuts") \
-    X(I, graph_max_cpu_pct, "SRCNN_GRAPH_MAX_CPU_PCT", 50,  "0...100, 0 = never fall back", "`srcnn_y_upscale2x_f32_stream(use_graph = 1)`: hipGraph replay is kept only while the process's CPU time per replayed frame stays below this share of the frame's wall time (on ROCm 7.2 a runtime thread spins from launch to completion: ~100 %); above it the stream goes on with plain launches -- same kernels, same overlap") \
+    X(I, graph_max_cpu_pct, "SRCNN_GRAPH_MAX_CPU_PCT", 10,  "0...100, 0 = never fall back", "`srcnn_y_upscale2x_f32_stream(use_graph = 1)`: hipGraph replay is kept only while the process's CPU time per replayed frame stays below this share of the frame's wall time (plain launches cost 6-8 % of a 4K frame; replay on ROCm 7.2 costs 20 % in a fresh process and ~100 % -- a runtime thread spinning from launch to completion -- in a process with more streams); above it the stream goes on with plain launches: same kernels, same overlap") \
     X(B, prefault,         "SRCNN_PREFAULT",         1,     "0/1", "pre-fault the fresh result pages of `ProcessSRCNN` in the background") \
     X(I, prefault_threads, "SRCNN_PREFAULT_THREADS", 1,     ">= 1", "helpers of that pre-faulting") \
     X(B, thp,              "SRCNN_THP",              1,     "0/1", "huge-page hint on large result blocks") \
