@@ -194,7 +194,8 @@ def cmd_destroy_with_dead_peer(rank, world, args):
 def main():
     cmd, rank, world, idfile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     args = sys.argv[5:]
-    S.init(0)
+    # one device per rank when the test asks for the REAL RCCL on a multi-GPU box; device 0 for everybody behind the stand-in
+    S.init(rank % max(1, S.device_count()) if os.environ.get("SRCNN_WORKER_DEVICE_PER_RANK") else 0)
     ident = exchange_id(idfile, rank)
     S.check(S.lib().srcnn_comm_init(ident, rank, world))
     out = globals()["cmd_" + cmd](rank, world, args)
