@@ -168,12 +168,25 @@ def process_srcnn_wall(S):
                      "MPix/s": round(4 * h * w / 1e6 / min(ts), 1),
                      "host_cpu_ms_per_call": round(sorted(cs)[len(cs) // 2] * 1e3, 2)}
         ph = (C.c_double * 8)()
+        mhz_in_call = None
+        if h >= 2160:
+            # one more call with the in-kernel clock probe on (include/srcnn_amd_debug.h): the shader clock every layer-1+2 launch of
+            # the call ran at -- the same kernels run at ~2.35 GHz in the resident loop (`resident_layer12_mhz` below)
+            S.clock_probe(True)
+            o, osz = C.c_void_p(), C.c_uint(0)
+            rc = fn(img.ctypes.data, w, h, 3, 2.0, C.byref(o), C.byref(osz), None, None)
+            recs = S.clock_read(0)
+            S.clock_probe(False)
+            L.srcnn_delete_array(o)
+            if rc == 0 and recs:
+                mhz_in_call = [round(float(m)) for m, _us in recs]
         if L.srcnn_debug_process_phases(ph, 8) >= 6 and h >= 2160:
             # where the LAST call's time went (include/srcnn_amd_debug.h): milliseconds since the call's work began
             out[name]["phases_ms_last_call"] = {
                 "call_ms": round(ts[-1] * 1e3, 2), "setup_done": round(ph[0], 2), "first_band_queued": round(ph[1], 2),
                 "last_kernels_done": round(ph[2], 2), "last_band_landed": round(ph[3], 2), "fanned_out": round(ph[4], 2),
                 "bands": int(ph[5]),
+                "layer12_shader_mhz_per_band": mhz_in_call,
                 "note": "device busy from first_band_queued to last_kernels_done; before it: lane lease, tables, the first band's "
                         "stage-in (memcpy into page-locked staging + H2D); after it: the last band's D2H and its copy into the "
                         "caller's fresh new[] block"}
@@ -1013,6 +1026,17 @@ def main():
             per = sorted(evs[i].elapsed_ms(evs[i + 1]) for i in range(10))
             out["device_ms_per_step"] = {"median": round((per[4] + per[5]) / 2, 4), "min": round(per[0], 4), "max": round(per[-1], 4),
                                          "MPix/s_at_median": round(mpix_step / ((per[4] + per[5]) / 2 * 1e-3), 1), "steps": 10}
+            # the shader clock the layer-1+2 launches of this loop run at (in-kernel probe, 3 more steps): what the drop-in call's
+            # per-band clocks (process_srcnn_ms.*.phases_ms_last_call.layer12_shader_mhz_per_band) are to be held against
+            S.clock_probe(True)
+            for _ in range(3):
+                step()
+            S.sync()
+            recs = S.clock_read(0)
+            S.clock_probe(False)
+            if recs:
+                ms_ = sorted(float(m) for m, _us in recs)
+                out["resident_layer12_mhz"] = {"median": round(ms_[len(ms_) // 2]), "min": round(ms_[0]), "max": round(ms_[-1]), "launches": len(ms_)}
             # both generators: the headline above is `smooth`; `noise` is the worst case for rounding
             gens = {"smooth": round(value, 1)}
             load("noise")
