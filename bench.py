@@ -400,7 +400,7 @@ def baseline_configs(S):
 
 def roofline_all(stage_ms, n_out, in_px):
     """Every kernel of the strict path against ITS OWN bound: achieved, the peak or floor it is held to,
-    and the fraction.  stage_ms = device time per 4K -> 8K frame (all of its launches: a frame is two bands under the default scratch cap) from the HIP
+    and the fraction.  stage_ms = device time per 4K -> 8K frame (all of its launches: a frame is one band under the default scratch cap, more under a lower one) from the HIP
     events of the timed region."""
     CLK = 2.4e9
     SIMDS = 256 * 4
@@ -957,7 +957,7 @@ def main():
         avg12 = c12_ms / max(c12_n, 1)
         frames_timed = F * args.steps                            # frames this rank pushed through the timed region
         # One launch of the layer kernels = one BAND of a frame: a 7680x4320 frame holds 4.25 GB of layer-2 planes and the default
-        # scratch cap (SRCNN_MAX_WORKSPACE_MB = 2048) makes it two bands of 2160 rows.  Algorithmic work per launch = the
+        # scratch cap (SRCNN_MAX_WORKSPACE_MB = 4608) holds them, a lower cap makes it several bands.  Algorithmic work per launch = the
         # frame's, divided by the launches per frame (recomputed halo rows are not algorithmic work).
         launches_per_frame = max(1.0, c12_n / max(frames_timed, 1))
         px_per_launch = n_out / launches_per_frame

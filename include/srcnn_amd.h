@@ -112,9 +112,10 @@ int         srcnn_set_mode(int mode);              /* SRCNN_MODE_*; returns prev
 int         srcnn_get_mode(void);
 int         srcnn_device_name(char* buf, size_t cap);
 /* Upper bound, in bytes, on the layer-2 scratch (128 B per output pixel) one pass may hold; larger frames / bands
- * are produced in horizontal sub-bands with identical results.  Default 2 GiB or env SRCNN_MAX_WORKSPACE_MB: a
- * 3840x2160 -> 7680x4320 frame (4.25 GB of layer-2 planes) runs as two bands at the speed of one; down to 512 MiB banding
- * costs < 2 %, 256 MiB +9 %, below that the short bands fill the persistent grid badly (profiles/r06_lowmem.txt).
+ * are produced in horizontal sub-bands with identical results.  Default 4.5 GiB or env SRCNN_MAX_WORKSPACE_MB: a
+ * 3840x2160 -> 7680x4320 frame (4.25 GB of layer-2 planes) still runs as one pass.  Where memory is short the cap can go
+ * down a long way: 2 GiB (two bands) costs -1...+2 % depending on the box, 512 MiB +2 %, 256 MiB +9 %; below that the short
+ * bands fill the persistent grid badly (128 MiB +36 %; profiles/r06_lowmem.txt).
  * Returns the previous limit.  Applies to calls that start afterwards, including the bands of srcnn_process_u8.  A band is
  * never smaller than 16 rows (one tile row of the layer kernels), so a limit below 16 rows' worth is exceeded, not refused. */
 size_t      srcnn_set_workspace_limit(size_t bytes);
@@ -147,7 +148,7 @@ int   srcnn_event_elapsed_ms(void* start, void* stop, float* ms);   /* syncs on 
  * d_out: planar float32 Y', (2w)*(2h) (device memory)
  * Launches asynchronously on `stream` (NULL = default stream); scratch comes from a grow-only
  * per-stream workspace owned by the library, so steady-state calls do no allocation.  The scratch is
- * 128 B per output pixel; above a budget (env SRCNN_MAX_WORKSPACE_MB, default 2048) the frame is
+ * 128 B per output pixel; above a budget (env SRCNN_MAX_WORKSPACE_MB, default 4608) the frame is
  * produced in horizontal bands internally, with identical results.  Limits: 2^20 output rows, 2^31 pixels. */
 int srcnn_y_upscale2x_f32_dev(const float* d_in, unsigned w, unsigned h, float* d_out, void* stream);
 

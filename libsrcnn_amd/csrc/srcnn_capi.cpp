@@ -1031,7 +1031,7 @@ std::vector<unsigned> plan_cuts(unsigned R0, unsigned R1, unsigned dw, unsigned 
 }
 
 // Output rows [r0,r1).  The 32 layer-2 planes are the big scratch (128 B per output pixel).  A range whose planes
-// would exceed the workspace budget (default 2 GiB, SRCNN_MAX_WORKSPACE_MB) is produced in horizontal bands --
+// would exceed the workspace budget (default 4.5 GiB, SRCNN_MAX_WORKSPACE_MB) is produced in horizontal bands --
 // bit-identical to the whole range -- so a 16K x 16K output needs the same scratch as an 8K one.
 int y_path_range(Call& c, const float* d_in, unsigned w, unsigned h, unsigned dw, unsigned dh, int filter,
                  unsigned r0, unsigned r1, float* d_out)

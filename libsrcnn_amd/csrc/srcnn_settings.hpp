@@ -14,7 +14,7 @@
 #define SRCNN_SETTINGS(X)                                                                                                          \
     /* ---- host side ---- */                                                                                                        \
     X(S, devices,          "SRCNN_DEVICES",          "",    "unset = device 0, `all`, `0,1,...`", "contexts of a process that never calls `srcnn_init*` (an id may repeat: virtual contexts on one device)") \
-    X(I, max_workspace_mb, "SRCNN_MAX_WORKSPACE_MB", 2048, "MiB (API twin `srcnn_set_workspace_limit`)", "layer-2 scratch one pass may hold; larger ranges are banded, bit-identically (an 8K frame: two bands at no cost in time -- `profiles/r06_lowmem.txt`; 16384 until round 6)") \
+    X(I, max_workspace_mb, "SRCNN_MAX_WORKSPACE_MB", 4608, "MiB (API twin `srcnn_set_workspace_limit`)", "layer-2 scratch one pass may hold; larger ranges are banded, bit-identically.  The default holds a whole 7680x4320 output frame (4.25 GB); lower it where memory is short: 2048 costs -1...+2 % by box, 512 +2 %, 256 +9 % (`profiles/r06_lowmem.txt`); 16384 until round 6") \
     X(I, max_lanes,        "SRCNN_MAX_LANES",        4,     "1...64", "concurrent `ProcessSRCNN` calls per context before callers queue") \
     X(B, numa,             "SRCNN_NUMA",             1,     "0/1", "place page-locked staging on the device's NUMA node (the caller's memory policy is saved and restored)") \
     X(I, comm_timeout_ms,  "SRCNN_COMM_TIMEOUT_MS",  60000, "ms, 0 = none (API twin `srcnn_comm_set_timeout_ms`)", "deadline of every wait on a peer") \

@@ -55,7 +55,7 @@ def short(name):
 
 
 lines = ["# rocprofv3 summary `%s` (MI355X, `python3 bench.py`, strict mode, 3840x2160 -> 7680x4320 frames)\n" % tag]
-for sub, title in (("kt", "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras` (strict headline; every launch of a layer kernel is one band of a 3840x2160 -> 7680x4320 frame: two per frame under the default scratch cap)"), ("kt_f16", "`bench.py --tier fast_f16` (non-parity fused kernel)")):
+for sub, title in (("kt", "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras` (strict headline; every launch of a layer kernel is one band of a 3840x2160 -> 7680x4320 frame: one per frame under the default scratch cap)"), ("kt_f16", "`bench.py --tier fast_f16` (non-parity fused kernel)")):
     stats = one(sub + "/**/*_kernel_stats.csv")
     if not stats:
         continue
