@@ -13,7 +13,8 @@
 // STRICT kernels keep the reference's evaluation order and roundings exactly: one rounded fp32 product then
 // one rounded fp32 add per tap (no FMA; this TU is built with -ffp-contract=off and the pragma below), taps in
 // the reference's loop order, fp64 where the reference uses double.  The non-parity tiers are template
-// parameters / separate kernels and are never selected unless srcnn_set_mode asks for them.
+// parameters / separate kernels and are never selected unless srcnn_set_mode asks for them; -DSRCNN_STRICT_ONLY
+// (make STRICT_ONLY=1) compiles no instance of them at all.
 //
 // Data layout in HBM: every image is planar float32, row-major; activation stacks are [channel][row][col]
 // with a caller-given plane stride.  Weights live in __constant__ memory, re-laid out once on the host:
