@@ -314,8 +314,9 @@ int srcnn_comm_barrier(void* stream);
  * a new one) cannot be paired by the check and are caught by the deadline instead: every rank returns SRCNN_E_COMM after
  * SRCNN_COMM_TIMEOUT_MS, the communicator is aborted.  The tables the library derives itself depend on (width, height, ranks,
  * pieces) only -- never on a switch.
- * srcnn_comm_destroy drains the NULL stream, the streams made by srcnn_stream_create and the library's own comm stream under
- * the deadline; communication queued on a raw HIP stream of the caller's must be synchronised by the caller first. */
+ * srcnn_comm_destroy waits, under the same deadline, for everything that was queued through srcnn_comm_*: it records an event
+ * behind the last communication on every stream it was given -- a raw HIP stream of the caller's included, and an event stays
+ * valid after its stream is destroyed -- and aborts instead of destroying the communicator when one does not complete. */
 int srcnn_comm_wait(void* stream);
 int srcnn_comm_set_timeout_ms(int ms);
 

@@ -126,10 +126,30 @@ bool view(CommView& v)
 }
 // the streams communication was queued on since init (bounded; what srcnn_comm_destroy drains under the deadline)
 std::vector<hipStream_t> g_streams;
+// ... and, per stream, an event recorded behind the last communication queued on it: an event stays valid (and completes) after
+// its stream has been destroyed, so srcnn_comm_destroy can wait -- under the deadline -- for communication on a RAW HIP
+// stream of the caller's as well, which it must not query once the caller may have destroyed it
+std::vector<hipEvent_t> g_stream_events;      // parallel to g_streams; nullptr until the first mark
 void note_stream(hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (std::find(g_streams.begin(), g_streams.end(), s) == g_streams.end() && g_streams.size() < 64) g_streams.push_back(s);
+    if (std::find(g_streams.begin(), g_streams.end(), s) == g_streams.end() && g_streams.size() < 64) {
+        g_streams.push_back(s);
+        g_stream_events.push_back(nullptr);
+    }
+}
+void mark_stream(hipStream_t s)               // after communication has been queued on s
+{
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        const auto it = std::find(g_streams.begin(), g_streams.end(), s);
+        if (it == g_streams.end()) return;
+        hipEvent_t& slot = g_stream_events[it - g_streams.begin()];
+        if (!slot && hipEventCreateWithFlags(&slot, hipEventDisableTiming) != hipSuccess) { slot = nullptr; return; }
+        ev = slot;
+    }
+    (void)hipEventRecord(ev, s);
 }
 thread_local char g_cerr[256];
 
@@ -301,6 +321,8 @@ int srcnn_comm_init(const unsigned char id[SRCNN_COMM_ID_BYTES], int rank, int n
     g_comm = comm; g_token = token;
     g_rank = rank; g_nranks = nranks; g_device = cx->device;
     g_verified.clear();
+    for (hipEvent_t e : g_stream_events) if (e) (void)hipEventDestroy(e);
+    g_stream_events.clear();
     g_streams.clear();
     return SRCNN_OK;
 }
@@ -322,15 +344,29 @@ int srcnn_comm_destroy(void)
             // communicator is aborted -- which ends the spinning kernels -- instead of destroyed.
             const int ms = g_timeout_ms.load();
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
-            // only streams that are known to be alive: the NULL stream, the library's comm stream and streams from
-            // srcnn_stream_create that have not been destroyed since (querying a destroyed handle crashes inside the runtime);
-            // a caller that passed a raw HIP stream of its own drains it itself
+            // Streams are queried only when they are known to be alive: the NULL stream, the library's comm stream and streams
+            // from srcnn_stream_create that have not been destroyed since (querying a destroyed handle crashes inside the
+            // runtime).  Every stream communication was queued on -- a raw HIP stream of the caller's included -- also has an event
+            // behind its last communication (mark_stream), and events outlive their streams: those are waited for below.
             std::vector<hipStream_t> streams;
+            std::vector<hipEvent_t> marks;
             {
                 std::lock_guard<std::mutex> gk(srcnn::G.mu);
-                for (hipStream_t st : g_streams)
+                for (size_t i = 0; i < g_streams.size(); ++i) {
+                    hipStream_t st = g_streams[i];
                     if (!st || srcnn::G.stream_ctx.count(st)) streams.push_back(st);
+                    if (g_stream_events[i]) marks.push_back(g_stream_events[i]);
+                }
             }
+            for (hipEvent_t ev : marks) {
+                for (int n = 0; drained; ++n) {
+                    const hipError_t e = hipEventQuery(ev);
+                    if (e != hipErrorNotReady) break;
+                    if (ms > 0 && std::chrono::steady_clock::now() >= deadline) { drained = false; break; }
+                    if (n > 64) std::this_thread::sleep_for(std::chrono::microseconds(n < 2000 ? 50 : 500));
+                }
+            }
+            (void)hipGetLastError();
             if (g_comm_stream) streams.push_back(g_comm_stream);
             for (hipStream_t st : streams) {
                 for (int n = 0; drained; ++n) {
@@ -360,6 +396,8 @@ int srcnn_comm_destroy(void)
     g_events.clear();
     if (g_comm_stream) (void)hipStreamDestroy(g_comm_stream);
     g_comm_stream = nullptr;
+    for (hipEvent_t e : g_stream_events) if (e) (void)hipEventDestroy(e);
+    g_stream_events.clear();
     g_streams.clear();
     g_rank = 0; g_nranks = 1;
     return SRCNN_OK;
@@ -459,6 +497,7 @@ int srcnn_comm_gatherv_at_f32(const float* d_send, const size_t* counts, const s
             return SRCNN_E_HIP;
         }
     }
+    mark_stream(s);
     return SRCNN_OK;
 }
 
@@ -576,6 +615,7 @@ int srcnn_comm_allgather_f32(const float* d_send, size_t count, float* d_recv, v
     const ncclResult_t r = R.AllGather(d_send, d_recv, count, ncclFloat, v.comm, (hipStream_t)stream);
     if (watchdog().disarm(armed)) return comm_fail("all-gather: deadline missed while queueing; communicator aborted");
     NCCL_TRY(r);
+    mark_stream((hipStream_t)stream);
     return SRCNN_OK;
 }
 
@@ -590,6 +630,7 @@ int srcnn_comm_barrier(void* stream)
     const ncclResult_t r = R.AllReduce(g_token, g_token, 1, ncclFloat, ncclSum, v.comm, (hipStream_t)stream);
     if (watchdog().disarm(armed)) return comm_fail("barrier: deadline missed while queueing; communicator aborted");
     NCCL_TRY(r);
+    mark_stream((hipStream_t)stream);
     return srcnn_comm_wait(stream);
 }
 

@@ -223,6 +223,46 @@ def test_rccl_comm_single_rank(srcnn):
         S.check(L.srcnn_comm_destroy())
 
 
+def test_comm_destroy_after_the_callers_raw_stream_is_gone(srcnn):
+    """communication queued on a raw HIP stream of the CALLER's (not one from srcnn_stream_create) is waited for by
+    srcnn_comm_destroy through an event recorded behind it -- the stream itself is never queried, so a caller that has already
+    destroyed it cannot crash the drain (querying a destroyed handle dies inside the runtime)."""
+    import ctypes as C
+    S = srcnn
+    L = S.lib()
+    hip = None
+    for name in ("libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            hip = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        pytest.skip("no libamdhip64 to create a raw stream with")
+    ident = (C.c_ubyte * 128)()
+    S.check(L.srcnn_comm_unique_id(ident))
+    S.check(L.srcnn_comm_init(ident, 0, 1))
+    raw = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(raw), 1) == 0          # hipStreamNonBlocking
+    try:
+        x = np.arange(4096, dtype=np.float32)
+        src = S.DeviceBuffer.from_numpy(x)
+        dst = S.DeviceBuffer(x.nbytes)
+        S.check(L.srcnn_comm_allgather_f32(src.ptr, x.size, dst.ptr, raw))
+        S.check(L.srcnn_comm_barrier(raw))
+        assert hip.hipStreamSynchronize(raw) == 0
+        assert np.array_equal(dst.to_numpy(np.float32, x.shape), x)
+        S.check(L.srcnn_comm_barrier(raw))                             # still queued (or just done) when the stream goes
+    finally:
+        assert hip.hipStreamDestroy(raw) == 0
+        S.check(L.srcnn_comm_destroy())                                # waits on the event, never touches `raw`
+    # and the library is fine afterwards
+    S.check(L.srcnn_comm_unique_id(ident))
+    S.check(L.srcnn_comm_init(ident, 0, 1))
+    S.check(L.srcnn_comm_barrier(None))
+    S.check(L.srcnn_comm_destroy())
+
+
 def test_cli_srcnntest_butterfly(srcnn, golden, tmp_path):
     """The srcnntest front end (counterpart of the reference's src/test.cpp) on the butterfly sample:
     PPM in, PPM + conv-Y PGM out, both equal to the reference's published PNG pixels."""
