@@ -458,6 +458,9 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     // (profiles/r04_process_clock.txt: 10.8 ms per image blocking, 11.5 with two jobs in flight, for 9 ms of device work).
     const bool in_pinned = !small && pinned_by_library(J.rgb, n * d);
     const bool out_pinned = !small && pinned_by_library(J.out, (size_t)dw * dh * d) && (!J.conv || pinned_by_library(J.conv, (size_t)dw * dh));
+    // small images: caller buffers the library page-locked itself are used in place, everything else goes through the lane's staging
+    const bool small_in_locked = small && pinned_by_library(J.rgb, n * d);
+    const bool small_out_locked = small && pinned_by_library(J.out, (size_t)dw * dh * d) && (!J.conv || pinned_by_library(J.conv, (size_t)dw * dh));
     // ---- stage-in.  Small images: the share's source rows in one go, straight from the caller's (pageable) buffer.  Large
     //      images: band by band -- stage_rows(upto) brings source rows [staged, upto) through the page-locked staging to the
     //      device (and, on the plane path, splits them), so the first band's kernels start after a third of the copy and the
@@ -470,7 +473,14 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if (upto == staged) return SRCNN_OK;
         const size_t off = (size_t)staged * w * d, nbytes = (size_t)(upto - staged) * w * d;
         if (small) {
-            if (int r = copy_h2d_any(cx, d_rgb + off, J.rgb + off, nbytes, s)) return r;      // (pageable: through the bounce slots)
+            // through the lane's own page-locked staging, asynchronously on the lane's stream (a pageable pointer never goes to a
+            // HIP copy: HostBounce in srcnn_host.hpp; the call waits once, at its end)
+            const unsigned char* from = J.rgb + off;
+            if (!small_in_locked) {
+                memcpy(L.pin_in + (off - src_off), J.rgb + off, nbytes);
+                from = L.pin_in + (off - src_off);
+            }
+            HIP_TRY(hipMemcpyAsync(d_rgb + off, from, nbytes, hipMemcpyHostToDevice, s));
         } else {
             // on the lane's own input stream, so that the copy runs BESIDE the previous band's kernels.  The band's kernels may
             // not start before the rows are there: this thread waits for the copy (polling; the previous band keeps the device
@@ -508,6 +518,10 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
     };
     std::thread prefault;
     bool prefaulting = false;
+    if (small) {
+        if (!small_in_locked && (rc = grow_pinned(cx, L.pin_in, L.pin_in_n, src_bytes))) return rc;
+        if (!small_out_locked && (rc = grow_pinned(cx, L.pin_out, L.pin_out_n, out_bytes + share_px))) return rc;
+    }
     if (!small) {
         if (!in_pinned && (rc = grow_pinned(cx, L.pin_in, L.pin_in_n, src_bytes))) return rc;
         if (!out_pinned && (rc = grow_pinned(cx, L.pin_out, L.pin_out_n, out_bytes + share_px))) return rc;
@@ -581,9 +595,15 @@ int process_share(Ctx& cx, const ProcJob& J, unsigned R0, unsigned R1, bool one_
         if ((rc = stage_rows(hi))) return rc;
         if ((rc = run_band(R0, R1))) return rc;
         chain_out();
-        if ((rc = copy_d2h_any(cx, J.out + (size_t)R0 * dw * d, d_out, out_bytes, s))) return rc;
-        if (J.conv && (rc = copy_d2h_any(cx, J.conv + (size_t)R0 * dw, d_conv, share_px, s))) return rc;
+        unsigned char* to_rgb = small_out_locked ? J.out + (size_t)R0 * dw * d : L.pin_out;
+        unsigned char* to_conv = small_out_locked ? (J.conv ? J.conv + (size_t)R0 * dw : nullptr) : L.pin_out + out_bytes;
+        HIP_TRY(hipMemcpyAsync(to_rgb, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        if (J.conv) HIP_TRY(hipMemcpyAsync(to_conv, d_conv, share_px, hipMemcpyDeviceToHost, s));
         HIP_TRY(wait_stream(s));
+        if (!small_out_locked) {
+            memcpy(J.out + (size_t)R0 * dw * d, L.pin_out, out_bytes);
+            if (J.conv) memcpy(J.conv + (size_t)R0 * dw, L.pin_out + out_bytes, share_px);
+        }
         return SRCNN_OK;
     }
 
