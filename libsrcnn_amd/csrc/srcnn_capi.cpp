@@ -285,12 +285,22 @@ int make_context_locked(int device)
     auto cx = std::make_unique<Ctx>();
     cx->index = (int)G.ctxs.size();
     cx->device = device;
+    // SRCNN_TRACE: where the time of creating a context goes (the first one also pays for loading the code object)
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (settings().trace)
+            fprintf(stderr, "srcnn_init ctx %d: %-28s at %7.2f ms\n", cx->index, what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count());
+    };
     // __constant__ weights, the kernels' dynamic-LDS attributes and the fused tier's weight image are per DEVICE; a second
     // (virtual) context on the same device re-uploads identical bytes
     auto dw = std::make_unique<DevWeights>();
     build_dev_weights(*dw);
+    stamp("weights built on the host");
     HIP_TRY(upload_weights(*dw));
+    stamp("weights uploaded (module load)");
     HIP_TRY(conv12_mfma_prepare());
+    stamp("layer-1+2 kernel attributes");
 #ifndef SRCNN_STRICT_ONLY
     auto fw = std::make_unique<FusedF16Weights>();
     build_fused_f16_weights(*dw, *fw);
@@ -299,12 +309,17 @@ int make_context_locked(int device)
         Ctx* cx;
         ~FreeOnError() { if (cx) { (void)hipFree(cx->fused_w); cx->fused_w = nullptr; } }
     } guard{cx.get()};
+    stamp("fp16 tier weights built");
     if (int rc = copy_h2d_any(*cx, cx->fused_w, fw.get(), sizeof(FusedF16Weights), nullptr)) return rc;
+    stamp("fp16 tier weights uploaded");
     HIP_TRY(fused_f16_prepare());
+    stamp("fp16 tier kernel attributes");
     HIP_TRY(rs2d_prepare());
+    stamp("resampler kernel attributes");
     guard.cx = nullptr;
 #else
     HIP_TRY(rs2d_prepare());
+    stamp("resampler kernel attributes");
 #endif
     cx->num_cus = prop.multiProcessorCount;
     cx->numa_node = device_numa_node(device);
@@ -526,13 +541,20 @@ void HostBounce::release()
 {
     if (pin) (void)hipHostFree(pin);
     for (hipEvent_t& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    pin = nullptr;
+    pin = nullptr; slot = 0;
 }
 
 namespace {
-int bounce_ready(Ctx& cx, HostBounce& b)          // b.mu held
+int bounce_ready(Ctx& cx, HostBounce& b, size_t bytes)          // b.mu held; no copy of this context is in flight
 {
-    if (!b.pin && !(b.pin = static_cast<unsigned char*>(pinned_alloc(cx, 2 * HostBounce::kSlot)))) return SRCNN_E_DEVMEM;
+    size_t want = 1u << 20;
+    while (want < bytes && want < HostBounce::kSlot) want <<= 1;
+    if (want > b.slot) {
+        if (b.pin) (void)hipHostFree(b.pin);
+        b.slot = 0;
+        if (!(b.pin = static_cast<unsigned char*>(pinned_alloc(cx, 2 * want)))) return SRCNN_E_DEVMEM;
+        b.slot = want;
+    }
     for (hipEvent_t& e : b.ev)
         if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return SRCNN_OK;
@@ -552,16 +574,17 @@ int copy_h2d_any(Ctx& cx, void* d_dst, const void* h_src, size_t bytes, hipStrea
     }
     HostBounce& b = cx.bounce;
     std::lock_guard<std::mutex> lk(b.mu);
-    if (int rc = bounce_ready(cx, b)) return rc;
+    if (int rc = bounce_ready(cx, b, bytes)) return rc;
+    const size_t SLOT = b.slot;
     const unsigned char* src = static_cast<const unsigned char*>(h_src);
     unsigned char* dst = static_cast<unsigned char*>(d_dst);
     bool used[2] = {false, false};
-    for (size_t off = 0, i = 0; off < bytes; off += HostBounce::kSlot, ++i) {
+    for (size_t off = 0, i = 0; off < bytes; off += SLOT, ++i) {
         const int k = (int)(i & 1);
-        const size_t len = std::min(HostBounce::kSlot, bytes - off);
+        const size_t len = std::min(SLOT, bytes - off);
         if (used[k] && wait_event(b.ev[k]) != hipSuccess) return fail(SRCNN_E_HIP, "bounced H2D copy failed");
-        parallel_memcpy(b.pin + k * HostBounce::kSlot, src + off, len);
-        HIP_TRY(hipMemcpyAsync(dst + off, b.pin + k * HostBounce::kSlot, len, hipMemcpyHostToDevice, after));
+        parallel_memcpy(b.pin + k * SLOT, src + off, len);
+        HIP_TRY(hipMemcpyAsync(dst + off, b.pin + k * SLOT, len, hipMemcpyHostToDevice, after));
         HIP_TRY(hipEventRecord(b.ev[k], after));
         used[k] = true;
     }
@@ -580,25 +603,26 @@ int copy_d2h_any(Ctx& cx, void* h_dst, const void* d_src, size_t bytes, hipStrea
     }
     HostBounce& b = cx.bounce;
     std::lock_guard<std::mutex> lk(b.mu);
-    if (int rc = bounce_ready(cx, b)) return rc;
+    if (int rc = bounce_ready(cx, b, bytes)) return rc;
+    const size_t SLOT = b.slot;
     unsigned char* dst = static_cast<unsigned char*>(h_dst);
     const unsigned char* src = static_cast<const unsigned char*>(d_src);
     // chunk i+1 is on the copy engine while chunk i is copied out of its slot
-    const size_t nchunks = (bytes + HostBounce::kSlot - 1) / HostBounce::kSlot;
+    const size_t nchunks = (bytes + SLOT - 1) / SLOT;
     auto queue = [&](size_t i) -> int {
         const int k = (int)(i & 1);
-        const size_t off = i * HostBounce::kSlot, len = std::min(HostBounce::kSlot, bytes - off);
-        HIP_TRY(hipMemcpyAsync(b.pin + k * HostBounce::kSlot, src + off, len, hipMemcpyDeviceToHost, after));
+        const size_t off = i * SLOT, len = std::min(SLOT, bytes - off);
+        HIP_TRY(hipMemcpyAsync(b.pin + k * SLOT, src + off, len, hipMemcpyDeviceToHost, after));
         HIP_TRY(hipEventRecord(b.ev[k], after));
         return SRCNN_OK;
     };
     if (int rc = queue(0)) return rc;
     for (size_t i = 0; i < nchunks; ++i) {
         const int k = (int)(i & 1);
-        const size_t off = i * HostBounce::kSlot, len = std::min(HostBounce::kSlot, bytes - off);
+        const size_t off = i * SLOT, len = std::min(SLOT, bytes - off);
         if (wait_event(b.ev[k]) != hipSuccess) return fail(SRCNN_E_HIP, "bounced D2H copy failed");
         if (i + 1 < nchunks) { if (int rc = queue(i + 1)) return rc; }
-        parallel_memcpy(dst + off, b.pin + k * HostBounce::kSlot, len);
+        parallel_memcpy(dst + off, b.pin + k * SLOT, len);
     }
     return SRCNN_OK;
 }

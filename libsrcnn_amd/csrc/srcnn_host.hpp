@@ -165,7 +165,9 @@ struct NodeLane {
 // memcpy + DMA, double-buffered, at memcpy speed -- which is what the runtime's own staging path costs too.
 struct HostBounce {
     std::mutex mu;                      // one bounced copy at a time per context
-    unsigned char* pin = nullptr;       // 2 slots of kSlot bytes, allocated on first use
+    unsigned char* pin = nullptr;       // 2 slots of `slot` bytes, allocated on first use
+    size_t slot = 0;                    // grows with the largest copy seen, 1 MB ... kSlot: page-locking 32 MB costs 5-80 ms, and
+                                        // the first copy of a process is the 50 KB weight image of srcnn_init
     hipEvent_t ev[2] = {nullptr, nullptr};
     static constexpr size_t kSlot = 16u << 20;
     void release();
