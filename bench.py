@@ -352,7 +352,9 @@ def baseline_configs(S):
             "warm_resident_min_ms": round(c2["warm_resident_min_ms"], 3),
             "MPix/s_warm_resident": round(n / (c2["warm_resident_median_ms"] * 1e-3), 1),
             "note": "fresh process; cold_first_call / warm_median: srcnn_y_upscale2x_f32 on pageable host float32 in and out "
-                    "(H2D + path + D2H, blocking); warm_resident: device pointers, call + device sync; device_init = srcnn_init"}
+                    "(H2D + path + D2H, blocking; the first call also page-locks the 2 x 16 MB bounce slots pageable memory travels "
+                    "through and allocates the device scratch); warm_resident: device pointers, call + device sync; device_init = "
+                    "srcnn_init (its first touch of the device loads the code object: 50-250 ms by box)"}
     else:
         out["2_single_1080p_frame"] = {"error": r.stderr[-300:]}
     # #3: batch of 64 resident 1080p frames, one call per step
